@@ -1,0 +1,216 @@
+/* liblbm_hip.so — C ABI of the MI355X (gfx950) kernels for the LBM online point-tracking step.
+ *
+ * This is the drop-in boundary of the hot path: plain pointers and sizes, no torch types.  Every
+ * pointer is DEVICE memory owned by the caller (in this repo: PyTorch-allocated tensors, passed as
+ * tensor.data_ptr()); the library allocates nothing, keeps no hidden state (the ring-buffer head is a
+ * caller-held int) and enqueues all work on the caller's HIP stream without synchronising.
+ * All functions return 0 on success and a negative value on error; the message is available from
+ * lbm_hip_last_error() (thread-local).  Nothing throws across the ABI.
+ *
+ * Reference citations are file:line in George-Zhuang/lbm (`/root/reference`).
+ * Conventions: C = 256 channels, 4 heads x 64, 4 pyramid levels; "R" = B*N tracked points.
+ */
+#ifndef LBM_HIP_H
+#define LBM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* lbm_stream_t; /* hipStream_t */
+
+#define LBM_HIP_ABI_VERSION 1
+#define LBM_HIP_MAX_LAYERS 8
+
+int lbm_hip_version(void);
+const char* lbm_hip_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Dense block.  Y[M,N] = act(X[M,K] . W[N,K]^T + bias[N]) + res_scale * RES[(m / res_div) % res_mod, :]
+ * then, if ln_gamma != NULL (N must be 256): Y = LayerNorm(Y) * gamma + beta, rows with keep[m] == 0
+ * replaced by fallback[m, :], and Yn (optional) = Y / max(|Y|_2, 1e-12).
+ * Replaces: nn.Linear / 1x1 nn.Conv2d / nn.LayerNorm / MLP call sites of transformer.py:114-149,
+ * 268-338, 343-355; msdeformattn.py:146-153,179; backbone.py:53-63.  act: 0 none, 1 exact GELU.
+ * `batch` > 1 repeats the product with element strides sX/sW/sB/sY/sR (gridDim.z).
+ * Requirements: K % 32 == 0, ldx/ldw % 4 == 0, X/W 16-byte aligned.                            */
+typedef struct {
+  const float* X; const float* W; const float* bias; float* Y; const float* res;
+  int32_t M, N, K, ldx, ldw, ldy, ldres, res_div, res_mod;
+  float res_scale;
+  int32_t act, batch;
+  int64_t sX, sW, sB, sY, sR;
+  const float* ln_gamma; const float* ln_beta; const uint8_t* keep; const float* fallback; float* Yn;
+} lbm_hip_linear_desc;
+int lbm_hip_linear(const lbm_hip_linear_desc* d, lbm_stream_t stream);
+
+/* Row-wise LayerNorm over C = 256 (+ optional keep/fallback select and L2-normalised copy).
+ * Replaces nn.LayerNorm (transformer.py:31,163,...) and the valid-row scatter of transformer.py:279,301. */
+int lbm_hip_layernorm(const float* X, const float* gamma, const float* beta, float* Y, int32_t rows,
+                      const uint8_t* keep, const float* fallback, float* Yn, lbm_stream_t stream);
+
+/* Y = X / max(|X|_2, 1e-12) per 256-channel row.  Replaces F.normalize (transformer.py:207-212). */
+int lbm_hip_l2norm(const float* X, int64_t ldx, float* Y, int64_t ldy, int64_t rows, lbm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Single-query 4-head attention read-out over a per-point sequence of S rows (memory ring buffer or
+ * lattice tokens).  U[R,4,256] are the per-head queries already mapped to key space
+ * (u_h = Wk_h^T (Wq_h x + bq_h) / 8); out[R,4,256] = sum_j softmax_j(u_h . (seq_j + temb_j)) seq_j.
+ * Logical position j lives in physical slot (ring_head + j) % S; masks are in physical order,
+ * non-zero = ignore; valid[r] = 0 when every position of row r is ignored (then out[r] = 0).
+ * Replaces the nn.MultiheadAttention calls of transformer.py:272, 294, 333 (together with two
+ * lbm_hip_linear calls using weights folded by lbm_amd/packing.py).                              */
+int lbm_hip_attn_readout(const float* U, const float* seq, int64_t point_stride, int64_t slot_stride,
+                         int32_t S, int32_t ring_head, const float* temb, const uint8_t* mask_a,
+                         const uint8_t* mask_b, float* out, uint8_t* valid, int32_t R, lbm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * tokens[B, L, 256], level 0 in rows [0, h*w): fills levels 1..3 (avg-pool 2/4/8) in place.
+ * Replaces LBMTransformer.get_multiscale_feats (transformer.py:51-71).                          */
+int lbm_hip_pyramid(float* tokens, int32_t B, int32_t h, int32_t w, lbm_stream_t stream);
+
+/* Correlation maps F[n_layers, B, h*w, 256] such that corr = q_hat . F^T + bias reproduces
+ * LBMTransformerLayer.correlation (transformer.py:193-229).  corr_mix_host: n_layers x 4 corr_conv
+ * weights in HOST memory; inv_norm[B, L] is scratch.                                            */
+int lbm_hip_corr_maps(const float* tokens, float* inv_norm, float* F, const float* corr_mix_host,
+                      int32_t n_layers, int32_t B, int32_t h, int32_t w, lbm_stream_t stream);
+
+/* Top-k per row (ties -> lowest index) + cell centres (x, y) in network pixels.
+ * Replaces torch.topk + indices_to_coords (transformer.py:307-308, coord_utils.py:4-29).        */
+int lbm_hip_topk(const float* corr, int64_t ld, int32_t P, int32_t k, int32_t rows, int32_t grid_w,
+                 int32_t stride_px, int32_t* idx_out, float* ref_out, float* val_out, lbm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Multi-scale deformable attention sampling core = multi_scale_deformable_attn_pytorch
+ * (msdeformattn.py:188-235) fused with the offset normalisation / softmax of
+ * MultiScaleDeformableAttention.forward (msdeformattn.py:150-170).  See msda.hpp for the two modes. */
+typedef struct {
+  const float* value; int64_t v_batch_stride; int32_t ldv;
+  int32_t lvl_h[4], lvl_w[4], lvl_start[4];
+  int32_t B, N, k, P;
+  const float* offlog; int32_t ld_offlog, logit_col;
+  const float* ref; float net_w, net_h;
+  const float* loc; const float* attw;
+  float* out;
+} lbm_hip_msda_desc;
+int lbm_hip_msda_sample(const lbm_hip_msda_desc* d, lbm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Encoder side.  preprocess: backbone.py:181-183; upcat: backbone.py:57-62 (pixel-major 64-channel
+ * maps -> [B*h*w, 192]); sample_queries: lbm_online.py:72-81 / backbone.py:88-92.               */
+int lbm_hip_preprocess(const float* frames, int64_t frame_bstride, float* out, int32_t B, int32_t H, int32_t W,
+                       int32_t oh, int32_t ow, lbm_stream_t stream);
+int lbm_hip_upcat(const float* p1, const float* p2, const float* p3, float* out, int32_t B, int32_t h, int32_t w,
+                  lbm_stream_t stream);
+int lbm_hip_sample_queries(const float* tokens, int64_t tok_bstride, int32_t ld, const float* pts, float* out,
+                           int32_t B, int32_t N, int32_t h, int32_t w, int32_t net_h, int32_t net_w,
+                           lbm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Whole tracking step = LBMTransformer.forward (transformer.py:74-151) + the state roll and output
+ * scaling of LBM_online.online_forward (lbm_online.py:143-156), enqueued as one call.
+ * Weight table layout: see the LBM_W_* indices below (built by lbm_amd/packing.py).             */
+#define LBM_W_ATTN_G 0      /* [1024,256]  per-head Wk_h^T Wq_h / 8, heads stacked           */
+#define LBM_W_ATTN_GB 1     /* [1024]                                                         */
+#define LBM_W_ATTN_TEMB 2   /* [M,256] time embedding of the past slots (NULL for lattice update) */
+#define LBM_W_ATTN_HM 3     /* [256,1024] per-head Wo[:,h] Wv_h, heads concatenated along K   */
+#define LBM_W_ATTN_HB 4     /* [256]                                                          */
+#define LBM_W_ATTN_LN1G 5
+#define LBM_W_ATTN_LN1B 6
+#define LBM_W_ATTN_F1W 7    /* [1024,256] */
+#define LBM_W_ATTN_F1B 8
+#define LBM_W_ATTN_F2W 9    /* [256,1024] */
+#define LBM_W_ATTN_F2B 10
+#define LBM_W_ATTN_LN2G 11
+#define LBM_W_ATTN_LN2B 12
+#define LBM_W_ATTN_COUNT 13
+
+#define LBM_W_MSDA_OLW 0    /* [48P,256] sampling_offsets (32P rows) then attention_weights (16P rows) */
+#define LBM_W_MSDA_OLB 1
+#define LBM_W_MSDA_OUTW 2   /* [256,256] output_proj */
+#define LBM_W_MSDA_OUTB 3
+#define LBM_W_MSDA_LN1G 4
+#define LBM_W_MSDA_LN1B 5
+#define LBM_W_MSDA_F1W 6
+#define LBM_W_MSDA_F1B 7
+#define LBM_W_MSDA_F2W 8
+#define LBM_W_MSDA_F2B 9
+#define LBM_W_MSDA_LN2G 10
+#define LBM_W_MSDA_LN2B 11
+#define LBM_W_MSDA_COUNT 12
+
+/* per layer i, base = i * LBM_W_LAYER_COUNT */
+#define LBM_W_LAYER_COLL 0
+#define LBM_W_LAYER_STREAM 13
+#define LBM_W_LAYER_LATTICE 26
+#define LBM_W_LAYER_UPDATE 38
+#define LBM_W_LAYER_RHO_W 51  /* [1,256] reference_rho */
+#define LBM_W_LAYER_RHO_B 52
+#define LBM_W_LAYER_COUNT 53
+/* after the layers, base = n_layers * LBM_W_LAYER_COUNT */
+#define LBM_W_HEAD_OFFSET 0
+#define LBM_W_HEAD_CMEM 12
+#define LBM_W_HEAD_VIS 24
+#define LBM_W_HEAD_OFFH_W0 36 /* offset_head.net.0 [256,256] */
+#define LBM_W_HEAD_OFFH_B0 37
+#define LBM_W_HEAD_OFFH_W3 38 /* offset_head.net.3 [2,256] */
+#define LBM_W_HEAD_OFFH_B3 39
+#define LBM_W_HEAD_VISH_W0 40
+#define LBM_W_HEAD_VISH_B0 41
+#define LBM_W_HEAD_VISH_W3 42
+#define LBM_W_HEAD_VISH_B3 43
+#define LBM_W_HEAD_VPROJ_W 44 /* [(n_layers+3)*256, 256] value_proj of lattice_0..n-1, offset, collision_mem, vis */
+#define LBM_W_HEAD_VPROJ_B 45
+#define LBM_W_HEAD_COUNT 46
+
+typedef struct {
+  /* geometry */
+  int32_t B, N, M, n_layers;
+  int32_t topk[LBM_HIP_MAX_LAYERS];
+  int32_t net_h, net_w, stride;         /* 384, 512, 4 */
+  int32_t n_points, n_points_cmem;      /* 9, 4 */
+  int32_t ring_head;                    /* physical slot holding the oldest memory entry */
+  int32_t update_state;                 /* 1: overwrite slot ring_head of memories and masks (state roll) */
+  float vis_threshold;                  /* 0.8 (lbm.py:17) */
+  float img_h, img_w;                   /* caller frame size for the coords output */
+  float corr_mix[LBM_HIP_MAX_LAYERS * 4]; /* corr_conv.weight per layer */
+  float corr_bias[LBM_HIP_MAX_LAYERS];
+  /* weights */
+  const float* const* weights;          /* HOST array of DEVICE pointers, LBM_W_* layout */
+  int32_t n_weights;
+  /* inputs */
+  const float* tokens;                  /* [B, L, 256] pyramid (levels filled) */
+  const float* query;                   /* [B, N, 256] initial point tokens */
+  float* stream_mem;                    /* [B, N, M, 256] ring buffers */
+  float* coll_mem;
+  uint8_t* vis_mask;                    /* [B, N, M] physical slot order */
+  uint8_t* mem_mask;
+  const uint8_t* queried;               /* [B, N] or NULL (all queried) */
+  /* outputs (optional unless noted) */
+  float* coords;                        /* [B, N, 2] caller pixels */
+  float* vis;                           /* [B, N] logits (required) */
+  float* rho;                           /* [B, N] logits (required) */
+  float* offset;                        /* [B, N, 2] network pixels (required) */
+  float* stream_out;                    /* [B, N, 256] memory['stream'] */
+  float* coll_out;                      /* [B, N, 256] memory['collision'] */
+  float* ref_points[LBM_HIP_MAX_LAYERS];/* per layer [B, N, k, 2] network pixels */
+  int32_t* topk_idx[LBM_HIP_MAX_LAYERS];/* per layer [B, N, k] */
+  float* ref_rho[LBM_HIP_MAX_LAYERS];   /* per layer [B, N, k] */
+  float* corr[LBM_HIP_MAX_LAYERS];      /* per layer [B, N, h*w] (training-style output; slow path) */
+  /* workspace */
+  void* workspace;
+  uint64_t workspace_bytes;
+} lbm_hip_step_desc;
+
+/* bytes of workspace lbm_hip_track_step needs for this geometry (only B, N, M, n_layers, topk, net_* are read) */
+uint64_t lbm_hip_step_workspace_bytes(const lbm_hip_step_desc* d);
+int lbm_hip_track_step(const lbm_hip_step_desc* d, lbm_stream_t stream);
+
+/* debugging aid for parity tests: byte offset of a named intermediate inside the workspace, or -1 */
+int64_t lbm_hip_step_workspace_offset(const lbm_hip_step_desc* d, const char* name);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LBM_HIP_H */

@@ -1,0 +1,380 @@
+// C ABI of liblbm_hip.so (include/lbm_hip.h) and the per-frame step orchestration.
+#include <stdarg.h>
+#include <string.h>
+
+#include "../../include/lbm_hip.h"
+#include "attn.hpp"
+#include "common.hpp"
+#include "encoder.hpp"
+#include "final.hpp"
+#include "gemm.hpp"
+#include "msda.hpp"
+#include "pyramid.hpp"
+#include "rows.hpp"
+
+namespace lbm {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    return -1;
+  }
+  return 0;
+}
+
+// ---- workspace layout of the step --------------------------------------------------------------
+struct StepLayout {
+  long long R, Q, L, P0, kmax;
+  int n_vmaps;
+  struct Item {
+    const char* name;
+    unsigned long long off, bytes;
+  };
+  Item items[32];
+  int n = 0;
+  unsigned long long total = 0;
+  unsigned long long add(const char* name, unsigned long long bytes) {
+    const unsigned long long off = total;
+    items[n++] = Item{name, off, bytes};
+    total += (bytes + 255ull) & ~255ull;
+    return off;
+  }
+  long long find(const char* name) const {
+    for (int i = 0; i < n; ++i)
+      if (strcmp(items[i].name, name) == 0) return (long long)items[i].off;
+    return -1;
+  }
+};
+
+static int build_layout(const lbm_hip_step_desc* d, StepLayout& lay) {
+  LBM_REQUIRE(d != nullptr, "step: null descriptor");
+  LBM_REQUIRE(d->B >= 1 && d->N >= 0 && d->M >= 1 && d->M <= 4096, "step: bad B/N/M (%d, %d, %d)", d->B, d->N, d->M);
+  LBM_REQUIRE(d->n_layers >= 1 && d->n_layers <= LBM_HIP_MAX_LAYERS, "step: n_layers=%d out of range", d->n_layers);
+  LBM_REQUIRE(d->stride == 4 && d->net_h % 32 == 0 && d->net_w % 32 == 0 && d->net_h > 0 && d->net_w > 0,
+              "step: network input %dx%d (stride %d) must be a multiple of 32 with stride 4", d->net_h, d->net_w, d->stride);
+  int kmax = 1;
+  for (int i = 0; i < d->n_layers; ++i) {
+    LBM_REQUIRE(d->topk[i] >= 1 && d->topk[i] <= 16, "step: topk[%d]=%d out of range", i, d->topk[i]);
+    if (d->topk[i] > kmax) kmax = d->topk[i];
+  }
+  LBM_REQUIRE(d->topk[d->n_layers - 1] == 1, "step: the last layer must select exactly one region (transformer.py:17)");
+  const int h = d->net_h / d->stride, w = d->net_w / d->stride;
+  lay.P0 = (long long)h * w;
+  lay.L = lay.P0 + lay.P0 / 4 + lay.P0 / 16 + lay.P0 / 64;
+  lay.R = (long long)d->B * d->N;
+  lay.kmax = kmax;
+  lay.Q = lay.R * kmax;
+  lay.n_vmaps = d->n_layers + 3;
+  const unsigned long long f = sizeof(float);
+  lay.add("value", (unsigned long long)d->B * lay.L * lay.n_vmaps * LBM_C * f);
+  lay.add("inv_norm", (unsigned long long)d->B * lay.L * f);
+  lay.add("corr_maps", (unsigned long long)d->n_layers * d->B * lay.P0 * LBM_C * f);
+  lay.add("corr", (unsigned long long)lay.R * lay.P0 * f);
+  lay.add("U", (unsigned long long)lay.R * 1024 * f);
+  lay.add("mbar", (unsigned long long)lay.R * 1024 * f);
+  lay.add("hid", (unsigned long long)lay.Q * 1024 * f);
+  lay.add("ta", (unsigned long long)lay.R * LBM_C * f);
+  lay.add("tb", (unsigned long long)lay.R * LBM_C * f);
+  lay.add("tc", (unsigned long long)lay.R * LBM_C * f);
+  lay.add("x0", (unsigned long long)lay.R * LBM_C * f);
+  lay.add("x1", (unsigned long long)lay.R * LBM_C * f);
+  lay.add("qn", (unsigned long long)lay.R * LBM_C * f);
+  lay.add("valid", (unsigned long long)lay.R);
+  lay.add("idx", (unsigned long long)lay.Q * sizeof(int));
+  lay.add("ref", (unsigned long long)lay.Q * 2 * f);
+  lay.add("offlog", (unsigned long long)lay.R * 48 * 16 * f);
+  lay.add("samp", (unsigned long long)lay.Q * LBM_C * f);
+  lay.add("la", (unsigned long long)lay.Q * LBM_C * f);
+  lay.add("lb", (unsigned long long)lay.Q * LBM_C * f);
+  lay.add("pred", (unsigned long long)lay.R * 2 * f);
+  lay.add("coll_tok", (unsigned long long)lay.R * LBM_C * f);
+  return 0;
+}
+
+struct Step {
+  const lbm_hip_step_desc* d;
+  StepLayout lay;
+  hipStream_t s;
+  char* ws;
+  int h, w;
+  template <typename T>
+  T* buf(const char* name) {
+    return reinterpret_cast<T*>(ws + lay.find(name));
+  }
+  const float* W(int idx) const { return d->weights[idx]; }
+
+  int linear(const float* X, int ldx, const float* Wt, const float* b, float* Y, int ldy, int M, int N, int K, int act = ACT_NONE,
+             const float* res = nullptr, int res_div = 1, float res_scale = 1.f, const float* g = nullptr, const float* be = nullptr,
+             const uint8_t* keep = nullptr, const float* fallback = nullptr, float* Yn = nullptr) {
+    GemmArgs a;
+    a.X = X; a.ldx = ldx; a.W = Wt; a.ldw = K; a.bias = b; a.Y = Y; a.ldy = ldy; a.M = M; a.N = N; a.K = K; a.act = act;
+    a.res = res; a.ldres = LBM_C; a.res_div = res_div; a.res_scale = res_scale;
+    a.ln_gamma = g; a.ln_beta = be; a.keep = keep; a.fallback = fallback; a.Yn = Yn;
+    return gemm(a, s);
+  }
+
+  // memory / lattice-update attention block: x_in [R,256] -> x_out [R,256]
+  int attn_block(int wb, const float* x_in, float* x_out, const float* seq, long long point_stride, int S, int ring_head,
+                 bool masked, float* Yn) {
+    const int R = (int)lay.R;
+    float* U = buf<float>("U");
+    float* mbar = buf<float>("mbar");
+    float* hid = buf<float>("hid");
+    float* y = buf<float>("tc");
+    uint8_t* valid = masked ? buf<uint8_t>("valid") : nullptr;
+    if (linear(x_in, LBM_C, W(wb + LBM_W_ATTN_G), W(wb + LBM_W_ATTN_GB), U, 1024, R, 1024, LBM_C)) return -1;
+    AttnArgs a;
+    a.U = U; a.seq = seq; a.point_stride = point_stride; a.slot_stride = LBM_C; a.S = S; a.ring_head = ring_head;
+    a.temb = masked ? W(wb + LBM_W_ATTN_TEMB) : nullptr;
+    a.mask_a = masked ? d->vis_mask : nullptr;
+    a.mask_b = masked ? d->mem_mask : nullptr;
+    a.out = mbar; a.valid = valid; a.R = R;
+    if (attn_readout(a, s)) return -1;
+    if (linear(mbar, 1024, W(wb + LBM_W_ATTN_HM), W(wb + LBM_W_ATTN_HB), y, LBM_C, R, LBM_C, 1024, ACT_NONE, x_in, 1, 1.f,
+               W(wb + LBM_W_ATTN_LN1G), W(wb + LBM_W_ATTN_LN1B)))
+      return -1;
+    if (linear(y, LBM_C, W(wb + LBM_W_ATTN_F1W), W(wb + LBM_W_ATTN_F1B), hid, 1024, R, 1024, LBM_C, ACT_GELU)) return -1;
+    return linear(hid, 1024, W(wb + LBM_W_ATTN_F2W), W(wb + LBM_W_ATTN_F2B), x_out, LBM_C, R, LBM_C, 1024, ACT_NONE, y, 1, 1.f,
+                  W(wb + LBM_W_ATTN_LN2G), W(wb + LBM_W_ATTN_LN2B), valid, x_in, Yn);
+  }
+
+  // deformable block: token x [R,256] (replicated k times) sampled at ref [R,k,2] -> out [R*k,256]
+  int msda_block(int wb, int vmap, int P, const float* x, const float* ref, int k, float* out) {
+    const int R = (int)lay.R, Q = R * k;
+    float* offlog = buf<float>("offlog");
+    float* samp = buf<float>("samp");
+    float* la = buf<float>("la");
+    float* hid = buf<float>("hid");
+    const int ncol = 48 * P;
+    if (linear(x, LBM_C, W(wb + LBM_W_MSDA_OLW), W(wb + LBM_W_MSDA_OLB), offlog, ncol, R, ncol, LBM_C)) return -1;
+    MsdaArgs m;
+    m.value = buf<float>("value") + (long long)vmap * LBM_C;
+    m.ldv = lay.n_vmaps * LBM_C;
+    m.v_batch_stride = lay.L * m.ldv;
+    int st = 0;
+    for (int l = 0; l < 4; ++l) {
+      m.lvl_h[l] = h >> l; m.lvl_w[l] = w >> l; m.lvl_start[l] = st;
+      st += (h >> l) * (w >> l);
+    }
+    m.B = d->B; m.N = d->N; m.k = k; m.P = P;
+    m.offlog = offlog; m.ld_offlog = ncol; m.logit_col = 32 * P;
+    m.ref = ref; m.net_w = (float)d->net_w; m.net_h = (float)d->net_h;
+    m.out = samp;
+    if (msda_sample(m, s)) return -1;
+    // 2*q + output_proj(.)  (msdeformattn.py:185 adds the identity, transformer.py:321 adds the query again)
+    if (linear(samp, LBM_C, W(wb + LBM_W_MSDA_OUTW), W(wb + LBM_W_MSDA_OUTB), la, LBM_C, Q, LBM_C, LBM_C, ACT_NONE, x, k, 2.f,
+               W(wb + LBM_W_MSDA_LN1G), W(wb + LBM_W_MSDA_LN1B)))
+      return -1;
+    if (linear(la, LBM_C, W(wb + LBM_W_MSDA_F1W), W(wb + LBM_W_MSDA_F1B), hid, 1024, Q, 1024, LBM_C, ACT_GELU)) return -1;
+    return linear(hid, 1024, W(wb + LBM_W_MSDA_F2W), W(wb + LBM_W_MSDA_F2B), out, LBM_C, Q, LBM_C, 1024, ACT_NONE, la, 1, 1.f,
+                  W(wb + LBM_W_MSDA_LN2G), W(wb + LBM_W_MSDA_LN2B));
+  }
+
+  int run() {
+    const int R = (int)lay.R;
+    const int hb = d->n_layers * LBM_W_LAYER_COUNT;
+    // ---- per-frame, point-independent work ----
+    float* value = buf<float>("value");
+    const int nv = lay.n_vmaps * LBM_C;
+    if (linear(d->tokens, LBM_C, W(hb + LBM_W_HEAD_VPROJ_W), W(hb + LBM_W_HEAD_VPROJ_B), value, nv, (int)(d->B * lay.L), nv, LBM_C))
+      return -1;
+    float* F = buf<float>("corr_maps");
+    if (corr_maps(d->tokens, buf<float>("inv_norm"), F, d->corr_mix, d->n_layers, d->B, h, w, s)) return -1;
+    if (R == 0) return 0;
+
+    float* x0 = buf<float>("x0");
+    float* x1 = buf<float>("x1");
+    float* ta = buf<float>("ta");
+    float* tb = buf<float>("tb");
+    float* qn = buf<float>("qn");
+    float* corr = buf<float>("corr");
+    int* idx = buf<int>("idx");
+    float* ref = buf<float>("ref");
+    float* lb = buf<float>("lb");
+    const float* x = d->query;
+    for (int i = 0; i < d->n_layers; ++i) {
+      const int lw = i * LBM_W_LAYER_COUNT;
+      const int k = d->topk[i];
+      // collision then streaming read-out of the two memories (transformer.py:257-302)
+      if (attn_block(lw + LBM_W_LAYER_COLL, x, ta, d->coll_mem, (long long)d->M * LBM_C, d->M, d->ring_head, true, nullptr)) return -1;
+      if (attn_block(lw + LBM_W_LAYER_STREAM, ta, tb, d->stream_mem, (long long)d->M * LBM_C, d->M, d->ring_head, true, qn)) return -1;
+      // correlation + top-k (transformer.py:306-308)
+      GemmArgs g;
+      g.X = qn; g.ldx = LBM_C; g.sX = (long long)d->N * LBM_C;
+      g.W = F + (long long)i * d->B * lay.P0 * LBM_C; g.ldw = LBM_C; g.sW = lay.P0 * LBM_C;
+      float* cdst = d->corr[i] ? d->corr[i] : corr;
+      g.Y = cdst; g.ldy = (int)lay.P0; g.sY = (long long)d->N * lay.P0;
+      g.M = d->N; g.N = (int)lay.P0; g.K = LBM_C; g.batch = d->B;
+      if (gemm(g, s)) return -1;
+      int* idst = d->topk_idx[i] ? d->topk_idx[i] : idx;
+      float* rdst = d->ref_points[i] ? d->ref_points[i] : ref;
+      if (topk_rows(cdst, lay.P0, (int)lay.P0, k, R, w, d->stride, idst, rdst, nullptr, s)) return -1;
+      // lattice deformable attention on the k regions (transformer.py:316-327)
+      if (msda_block(lw + LBM_W_LAYER_LATTICE, i, d->n_points, tb, rdst, k, lb)) return -1;
+      if (d->ref_rho[i]) {
+        if (linear(lb, LBM_C, W(lw + LBM_W_LAYER_RHO_W), W(lw + LBM_W_LAYER_RHO_B), d->ref_rho[i], 1, R * k, 1, LBM_C)) return -1;
+      }
+      // lattice update (transformer.py:330-338)
+      float* xn = (i & 1) ? x1 : x0;
+      if (attn_block(lw + LBM_W_LAYER_UPDATE, tb, xn, lb, (long long)k * LBM_C, k, 0, false, nullptr)) return -1;
+      x = xn;
+      if (i == d->n_layers - 1 && rdst != ref) {
+        if (hipMemcpyAsync(ref, rdst, (size_t)R * 2 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) {
+          set_error("step: ref copy failed");
+          return -1;
+        }
+      }
+    }
+    // ---- heads (transformer.py:103-149) ----
+    float* hidR = buf<float>("hid");
+    float* pred = buf<float>("pred");
+    float* coll_tok = buf<float>("coll_tok");
+    if (msda_block(hb + LBM_W_HEAD_OFFSET, d->n_layers, d->n_points, x, ref, 1, ta)) return -1;
+    if (linear(ta, LBM_C, W(hb + LBM_W_HEAD_OFFH_W0), W(hb + LBM_W_HEAD_OFFH_B0), hidR, LBM_C, R, LBM_C, LBM_C, ACT_GELU)) return -1;
+    if (offset_final(hidR, W(hb + LBM_W_HEAD_OFFH_W3), W(hb + LBM_W_HEAD_OFFH_B3), ref, (float)d->stride, d->offset, pred, R, s)) return -1;
+    if (msda_block(hb + LBM_W_HEAD_CMEM, d->n_layers + 1, d->n_points_cmem, x, pred, 1, coll_tok)) return -1;
+    if (msda_block(hb + LBM_W_HEAD_VIS, d->n_layers + 2, d->n_points, x, ref, 1, ta)) return -1;
+    if (linear(ta, LBM_C, W(hb + LBM_W_HEAD_VISH_W0), W(hb + LBM_W_HEAD_VISH_B0), hidR, LBM_C, R, LBM_C, LBM_C, ACT_GELU)) return -1;
+    StateFinalArgs f;
+    f.vis_hidden = hidR; f.w3 = W(hb + LBM_W_HEAD_VISH_W3); f.b3 = W(hb + LBM_W_HEAD_VISH_B3);
+    f.stream_tok = x; f.coll_tok = coll_tok; f.query_init = d->query; f.queried = d->queried;
+    f.stream_out = d->stream_out; f.coll_out = d->coll_out;
+    if (d->update_state) {
+      f.stream_mem = d->stream_mem; f.coll_mem = d->coll_mem; f.vis_mask = d->vis_mask; f.mem_mask = d->mem_mask;
+    }
+    f.M = d->M; f.ring_head = d->ring_head; f.vis_threshold = d->vis_threshold;
+    f.vis = d->vis; f.rho = d->rho; f.ref = ref; f.offset = d->offset; f.coords = d->coords;
+    f.net_w = (float)d->net_w; f.net_h = (float)d->net_h; f.img_w = d->img_w; f.img_h = d->img_h;
+    f.R = R;
+    return state_final(f, s);
+  }
+};
+
+}  // namespace lbm
+
+using namespace lbm;
+
+extern "C" {
+
+int lbm_hip_version(void) { return LBM_HIP_ABI_VERSION; }
+const char* lbm_hip_last_error(void) { return g_err; }
+
+int lbm_hip_linear(const lbm_hip_linear_desc* d, lbm_stream_t stream) {
+  LBM_REQUIRE(d && d->X && d->W && d->Y, "linear: null argument");
+  GemmArgs a;
+  a.X = d->X; a.W = d->W; a.bias = d->bias; a.Y = d->Y; a.res = d->res;
+  a.M = d->M; a.N = d->N; a.K = d->K; a.ldx = d->ldx; a.ldw = d->ldw; a.ldy = d->ldy; a.ldres = d->ldres;
+  a.res_div = d->res_div > 0 ? d->res_div : 1;
+  a.res_mod = d->res_mod > 0 ? d->res_mod : 0x7fffffff;
+  a.res_scale = d->res_scale; a.act = d->act; a.batch = d->batch > 0 ? d->batch : 1;
+  a.sX = d->sX; a.sW = d->sW; a.sB = d->sB; a.sY = d->sY; a.sR = d->sR;
+  a.ln_gamma = d->ln_gamma; a.ln_beta = d->ln_beta; a.keep = d->keep; a.fallback = d->fallback; a.Yn = d->Yn;
+  return gemm(a, (hipStream_t)stream);
+}
+
+int lbm_hip_layernorm(const float* X, const float* gamma, const float* beta, float* Y, int32_t rows, const uint8_t* keep,
+                      const float* fallback, float* Yn, lbm_stream_t stream) {
+  return layernorm_rows(X, gamma, beta, Y, rows, keep, fallback, Yn, (hipStream_t)stream);
+}
+
+int lbm_hip_l2norm(const float* X, int64_t ldx, float* Y, int64_t ldy, int64_t rows, lbm_stream_t stream) {
+  return l2norm_rows(X, ldx, Y, ldy, rows, (hipStream_t)stream);
+}
+
+int lbm_hip_attn_readout(const float* U, const float* seq, int64_t point_stride, int64_t slot_stride, int32_t S,
+                         int32_t ring_head, const float* temb, const uint8_t* mask_a, const uint8_t* mask_b, float* out,
+                         uint8_t* valid, int32_t R, lbm_stream_t stream) {
+  AttnArgs a;
+  a.U = U; a.seq = seq; a.point_stride = point_stride; a.slot_stride = slot_stride; a.S = S; a.ring_head = ring_head;
+  a.temb = temb; a.mask_a = mask_a; a.mask_b = mask_b; a.out = out; a.valid = valid; a.R = R;
+  return attn_readout(a, (hipStream_t)stream);
+}
+
+int lbm_hip_pyramid(float* tokens, int32_t B, int32_t h, int32_t w, lbm_stream_t stream) {
+  return pyramid_pool(tokens, B, h, w, (hipStream_t)stream);
+}
+
+int lbm_hip_corr_maps(const float* tokens, float* inv_norm, float* F, const float* corr_mix_host, int32_t n_layers, int32_t B,
+                      int32_t h, int32_t w, lbm_stream_t stream) {
+  return corr_maps(tokens, inv_norm, F, corr_mix_host, n_layers, B, h, w, (hipStream_t)stream);
+}
+
+int lbm_hip_topk(const float* corr, int64_t ld, int32_t P, int32_t k, int32_t rows, int32_t grid_w, int32_t stride_px,
+                 int32_t* idx_out, float* ref_out, float* val_out, lbm_stream_t stream) {
+  return topk_rows(corr, ld, P, k, rows, grid_w, stride_px, idx_out, ref_out, val_out, (hipStream_t)stream);
+}
+
+int lbm_hip_msda_sample(const lbm_hip_msda_desc* d, lbm_stream_t stream) {
+  LBM_REQUIRE(d != nullptr, "msda_sample: null descriptor");
+  MsdaArgs a;
+  a.value = d->value; a.v_batch_stride = d->v_batch_stride; a.ldv = d->ldv;
+  for (int l = 0; l < 4; ++l) {
+    a.lvl_h[l] = d->lvl_h[l]; a.lvl_w[l] = d->lvl_w[l]; a.lvl_start[l] = d->lvl_start[l];
+  }
+  a.B = d->B; a.N = d->N; a.k = d->k; a.P = d->P;
+  a.offlog = d->offlog; a.ld_offlog = d->ld_offlog; a.logit_col = d->logit_col;
+  a.ref = d->ref; a.net_w = d->net_w; a.net_h = d->net_h; a.loc = d->loc; a.attw = d->attw; a.out = d->out;
+  return msda_sample(a, (hipStream_t)stream);
+}
+
+int lbm_hip_preprocess(const float* frames, int64_t frame_bstride, float* out, int32_t B, int32_t H, int32_t W, int32_t oh,
+                       int32_t ow, lbm_stream_t stream) {
+  return preprocess(frames, frame_bstride, out, B, H, W, oh, ow, (hipStream_t)stream);
+}
+
+int lbm_hip_upcat(const float* p1, const float* p2, const float* p3, float* out, int32_t B, int32_t h, int32_t w,
+                  lbm_stream_t stream) {
+  return upcat(p1, p2, p3, out, B, h, w, (hipStream_t)stream);
+}
+
+int lbm_hip_sample_queries(const float* tokens, int64_t tok_bstride, int32_t ld, const float* pts, float* out, int32_t B,
+                           int32_t N, int32_t h, int32_t w, int32_t net_h, int32_t net_w, lbm_stream_t stream) {
+  return sample_queries(tokens, tok_bstride, ld, pts, out, B, N, h, w, net_h, net_w, (hipStream_t)stream);
+}
+
+uint64_t lbm_hip_step_workspace_bytes(const lbm_hip_step_desc* d) {
+  StepLayout lay;
+  if (build_layout(d, lay)) return 0;
+  return lay.total;
+}
+
+int64_t lbm_hip_step_workspace_offset(const lbm_hip_step_desc* d, const char* name) {
+  StepLayout lay;
+  if (build_layout(d, lay) || name == nullptr) return -1;
+  return lay.find(name);
+}
+
+int lbm_hip_track_step(const lbm_hip_step_desc* d, lbm_stream_t stream) {
+  Step st;
+  if (build_layout(d, st.lay)) return -1;
+  LBM_REQUIRE(d->weights && d->n_weights == d->n_layers * LBM_W_LAYER_COUNT + LBM_W_HEAD_COUNT,
+              "step: weight table has %d entries, expected %d", d->n_weights, d->n_layers * LBM_W_LAYER_COUNT + LBM_W_HEAD_COUNT);
+  LBM_REQUIRE(d->tokens && d->workspace, "step: null tokens/workspace");
+  LBM_REQUIRE(d->workspace_bytes >= st.lay.total, "step: workspace has %llu bytes, needs %llu",
+              (unsigned long long)d->workspace_bytes, (unsigned long long)st.lay.total);
+  LBM_REQUIRE(((uintptr_t)d->workspace & 255) == 0, "step: workspace must be 256-byte aligned");
+  LBM_REQUIRE(d->n_points >= 1 && d->n_points <= 16 && d->n_points_cmem >= 1 && d->n_points_cmem <= 16, "step: bad n_points");
+  LBM_REQUIRE(d->ring_head >= 0 && d->ring_head < d->M, "step: ring_head %d outside [0,%d)", d->ring_head, d->M);
+  if (st.lay.R > 0) {
+    LBM_REQUIRE(d->query && d->stream_mem && d->coll_mem && d->vis_mask && d->mem_mask, "step: null state pointer");
+    LBM_REQUIRE(d->vis && d->rho && d->offset, "step: vis/rho/offset outputs are required");
+  }
+  st.d = d;
+  st.s = (hipStream_t)stream;
+  st.ws = (char*)d->workspace;
+  st.h = d->net_h / d->stride;
+  st.w = d->net_w / d->stride;
+  return st.run();
+}
+
+}  // extern "C"

@@ -1,0 +1,72 @@
+// Shared device/host helpers for the LBM gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#define LBM_C 256          // embedding dim (lbm/configs/demo.yaml:10)
+#define LBM_HEADS 4        // attention heads (demo.yaml:11)
+#define LBM_HD 64          // head dim
+#define LBM_LEVELS 4       // pyramid levels (demo.yaml:12)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace lbm {
+
+// ---- error plumbing (never throw across the C ABI) --------------------------------------------
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+#define LBM_REQUIRE(cond, ...)                      \
+  do {                                              \
+    if (!(cond)) {                                  \
+      lbm::set_error(__VA_ARGS__);                  \
+      return -1;                                    \
+    }                                               \
+  } while (0)
+
+// ---- cross-lane helpers (wave = 64 lanes) -----------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// Sum over each aligned group of 16 lanes; every lane of the group gets the total.
+// row_ror:n rotates within a 16-lane row (dpp_ctrl 0x120 + n).
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_f<0x128>(v);
+  v += dpp_f<0x124>(v);
+  v += dpp_f<0x122>(v);
+  v += dpp_f<0x121>(v);
+  return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_f<0x128>(v));
+  v = fmaxf(v, dpp_f<0x124>(v));
+  v = fmaxf(v, dpp_f<0x122>(v));
+  v = fmaxf(v, dpp_f<0x121>(v));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  v = row16_sum(v);
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+  v = row16_max(v);
+  v = fmaxf(v, __shfl_xor(v, 16));
+  v = fmaxf(v, __shfl_xor(v, 32));
+  return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) {
+  // exact GELU, as nn.GELU() default (transformer.py:348, backbone.py:36)
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+}  // namespace lbm

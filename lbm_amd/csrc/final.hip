@@ -1,0 +1,88 @@
+// Head read-outs fused with the state update (transformer.py:119-120, 136-138, 147-149;
+// lbm_online.py:143-156).  One wave per point, lane = 4 channels.
+#include "final.hpp"
+
+namespace lbm {
+
+// offset = tanh(W3 · hidden + b3) * stride ;  pred = ref_last + offset
+__global__ __launch_bounds__(256) void offset_final_kernel(const float* __restrict__ hidden, const float* __restrict__ w3,
+                                                           const float* __restrict__ b3, const float* __restrict__ ref,
+                                                           float stride_px, float* __restrict__ offset,
+                                                           float* __restrict__ pred, int R) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const float4 hv = ld4(hidden + (long long)row * LBM_C + lane * 4);
+  const float4 wa = ld4(w3 + lane * 4), wb = ld4(w3 + LBM_C + lane * 4);
+  const float s0 = wave_sum(hv.x * wa.x + hv.y * wa.y + hv.z * wa.z + hv.w * wa.w) + b3[0];
+  const float s1 = wave_sum(hv.x * wb.x + hv.y * wb.y + hv.z * wb.z + hv.w * wb.w) + b3[1];
+  if (lane == 0) {
+    const float ox = tanhf(s0) * stride_px, oy = tanhf(s1) * stride_px;
+    offset[row * 2] = ox;
+    offset[row * 2 + 1] = oy;
+    pred[row * 2] = ref[row * 2] + ox;
+    pred[row * 2 + 1] = ref[row * 2 + 1] + oy;
+  }
+}
+
+int offset_final(const float* hidden, const float* w3, const float* b3, const float* ref, float stride_px, float* offset,
+                 float* pred, int R, hipStream_t stream) {
+  if (R == 0) return 0;
+  LBM_REQUIRE(hidden && w3 && b3 && ref && offset && pred, "offset_final: null argument");
+  hipLaunchKernelGGL(offset_final_kernel, dim3((R + 3) / 4), dim3(256), 0, stream, hidden, w3, b3, ref, stride_px, offset, pred, R);
+  return check_launch("offset_final");
+}
+
+__global__ __launch_bounds__(256) void state_final_kernel(StateFinalArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.R) return;
+  const float4 hv = ld4(a.vis_hidden + (long long)row * LBM_C + lane * 4);
+  const float4 wa = ld4(a.w3 + lane * 4), wb = ld4(a.w3 + LBM_C + lane * 4);
+  const float vis = wave_sum(hv.x * wa.x + hv.y * wa.y + hv.z * wa.z + hv.w * wa.w) + a.b3[0];
+  const float rho = wave_sum(hv.x * wb.x + hv.y * wb.y + hv.z * wb.z + hv.w * wb.w) + a.b3[1];
+  const bool queried = a.queried ? a.queried[row] != 0 : true;
+
+  // new memory rows: stream = post-layer token; collision = queried ? collision token : initial query
+  const long long off = (long long)row * LBM_C + lane * 4;
+  const float4 sv = ld4(a.stream_tok + off);
+  const float4 cv = queried ? ld4(a.coll_tok + off) : ld4(a.query_init + off);
+  if (a.stream_out) st4(a.stream_out + off, sv);
+  if (a.coll_out) st4(a.coll_out + off, cv);
+  if (a.stream_mem) {
+    const long long so = ((long long)row * a.M + a.ring_head) * LBM_C + lane * 4;
+    st4(a.stream_mem + so, sv);
+    st4(a.coll_mem + so, cv);
+  }
+  if (lane == 0) {
+    a.vis[row] = vis;
+    a.rho[row] = rho;
+    if (a.vis_mask) {
+      const float sg = 1.0f / (1.0f + expf(-vis));
+      a.vis_mask[(long long)row * a.M + a.ring_head] = sg < a.vis_threshold ? 1 : 0;   // lbm_online.py:146
+      a.mem_mask[(long long)row * a.M + a.ring_head] = queried ? 0 : 1;                 // lbm_online.py:145
+    }
+    if (a.coords) {
+      // lbm_online.py:150-156: coord = ref + offset, rescaled to the caller's frame size
+      const float x = a.ref[row * 2] + a.offset[row * 2];
+      const float y = a.ref[row * 2 + 1] + a.offset[row * 2 + 1];
+      a.coords[row * 2] = x / a.net_w * a.img_w;
+      a.coords[row * 2 + 1] = y / a.net_h * a.img_h;
+    }
+  }
+}
+
+int state_final(const StateFinalArgs& a, hipStream_t stream) {
+  if (a.R == 0) return 0;
+  LBM_REQUIRE(a.vis_hidden && a.w3 && a.b3 && a.stream_tok && a.coll_tok && a.query_init && a.vis && a.rho,
+              "state_final: null argument");
+  LBM_REQUIRE(a.stream_mem == nullptr || (a.coll_mem && a.M >= 1 && a.ring_head >= 0 && a.ring_head < a.M),
+              "state_final: bad ring description");
+  LBM_REQUIRE(a.vis_mask == nullptr || (a.mem_mask && a.M >= 1 && a.ring_head >= 0 && a.ring_head < a.M),
+              "state_final: bad mask description");
+  LBM_REQUIRE(a.coords == nullptr || (a.ref && a.offset && a.net_w > 0 && a.net_h > 0), "state_final: coords need ref/offset");
+  hipLaunchKernelGGL(state_final_kernel, dim3((a.R + 3) / 4), dim3(256), 0, stream, a);
+  return check_launch("state_final");
+}
+
+}  // namespace lbm

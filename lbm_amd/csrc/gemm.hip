@@ -1,0 +1,239 @@
+// Exact-fp32 GEMM on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+//   Y[m, n] = act( sum_k X[m, k] * W[n, k] + bias[n] ) + res_scale * RES[(m / res_div) % res_mod, n]
+//
+// This one kernel family carries every dense contraction of the tracking step: the attention
+// projections (transformer.py:272,294,333), the FFNs (transformer.py:343-355), value/output
+// projections of the deformable attention (msdeformattn.py:146,179), the sampling-offset /
+// attention-weight linears (msdeformattn.py:150-153), the correlation product (transformer.py:209-212)
+// and the encoder's 1x1 convolutions (backbone.py:53-63).
+//
+// Layout: both operands are K-contiguous ("NT"), staged global -> registers -> LDS in 16-byte pieces,
+// LDS rows padded by 4 floats so the per-lane ds_read_b128 fragment reads are conflict-free.  A lane
+// (r = lane & 31, h = lane >> 5) of the 32x32x2 MFMA supplies A[r][k = h] and B[k = h][r]; we feed it
+// k = 8*s + 4*h + j for j = 0..3 from one float4, which keeps A's and B's k assignment identical, so
+// the sum over k is complete after the four MFMAs of step s.
+//
+// Three tilings are instantiated and chosen by problem size (256 CUs need >= ~256 workgroups):
+//   BIG  128x128, 4 waves as 2x2, 2x2 MFMA tiles per wave      (large M*N: value_proj, correlation)
+//   MID   64x64,  4 waves as 2x2, one MFMA tile per wave
+//   SPK   32x32,  4 waves splitting each K chunk four ways, summed through LDS (M ~ 1e3 rows)
+#include "gemm.hpp"
+#include "rows.hpp"
+
+namespace lbm {
+
+struct GemmDev {
+  const float* X;
+  const float* W;
+  const float* bias;
+  float* Y;
+  const float* res;
+  int M, N, K;
+  int ldx, ldw, ldy, ldres;
+  int res_div, res_mod;
+  float res_scale;
+  int act;
+  long long sX, sW, sB, sY, sR;
+};
+
+template <int BM, int BN, int WM, int WN, int WK, int BK>
+__global__ __launch_bounds__(WM* WN* WK * 64) void gemm_f32_kernel(GemmDev a) {
+  constexpr int NT = WM * WN * WK * 64;
+  constexpr int LS = BK + 4;                 // padded LDS row stride (floats)
+  constexpr int TM = BM / WM / 32;           // 32x32 MFMA tiles per wave along M
+  constexpr int TN = BN / WN / 32;
+  constexpr int KW = BK / WK;                // k extent one wave consumes per chunk
+  static_assert(KW % 8 == 0, "each wave consumes k in groups of 8");
+  constexpr int A_F4 = BM * BK / 4;          // float4 pieces per A chunk
+  constexpr int B_F4 = BN * BK / 4;
+  constexpr int A_PER_T = (A_F4 + NT - 1) / NT;
+  constexpr int B_PER_T = (B_F4 + NT - 1) / NT;
+  constexpr int STAGE = (BM + BN) * LS;      // floats per staging buffer
+  constexpr int RED = (WK > 1) ? (WK - 1) * BM * BN : 0;
+  constexpr int LDS_FLOATS = (2 * STAGE > RED) ? 2 * STAGE : RED;
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wk = wave / (WM * WN);
+  const int wm = (wave / WN) % WM;
+  const int wn = wave % WN;
+  const int r = lane & 31;
+  const int h = lane >> 5;
+
+  const int z = blockIdx.z;
+  const float* __restrict__ X = a.X + z * a.sX;
+  const float* __restrict__ W = a.W + z * a.sW;
+  const int m0 = blockIdx.y * BM;
+  const int n0 = blockIdx.x * BN;
+
+  float4 ra[A_PER_T], rb[B_PER_T];
+
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < A_PER_T; ++i) {
+      const int f = tid + i * NT;
+      const int row = f / (BK / 4), c4 = f % (BK / 4);
+      ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (f < A_F4 && m0 + row < a.M) ra[i] = ld4(X + (long long)(m0 + row) * a.ldx + k0 + c4 * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER_T; ++i) {
+      const int f = tid + i * NT;
+      const int row = f / (BK / 4), c4 = f % (BK / 4);
+      rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (f < B_F4 && n0 + row < a.N) rb[i] = ld4(W + (long long)(n0 + row) * a.ldw + k0 + c4 * 4);
+    }
+  };
+  auto lstore = [&](int buf) {
+    float* As = lds + buf * STAGE;
+    float* Bs = As + BM * LS;
+#pragma unroll
+    for (int i = 0; i < A_PER_T; ++i) {
+      const int f = tid + i * NT;
+      const int row = f / (BK / 4), c4 = f % (BK / 4);
+      if (f < A_F4) st4(As + row * LS + c4 * 4, ra[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER_T; ++i) {
+      const int f = tid + i * NT;
+      const int row = f / (BK / 4), c4 = f % (BK / 4);
+      if (f < B_F4) st4(Bs + row * LS + c4 * 4, rb[i]);
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nk = a.K / BK;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) gload((kt + 1) * BK);
+    const float* As = lds + cur * STAGE;
+    const float* Bs = As + BM * LS;
+#pragma unroll
+    for (int s = 0; s < KW / 8; ++s) {
+      const int kk = wk * KW + s * 8 + 4 * h;
+      float4 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = ld4(As + ((wm * TM + i) * 32 + r) * LS + kk);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = ld4(Bs + ((wn * TN + j) * 32 + r) * LS + kk);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+    if (kt + 1 < nk) lstore(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  if constexpr (WK > 1) {
+    // sum the K-split partials: waves wk > 0 park their tiles in LDS, wave group 0 adds them.
+    float* red = lds;
+    if (wk > 0) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            red[(((wk - 1) * WM * WN + wm * WN + wn) * TM * TN + i * TN + j) * 1024 + e * 64 + lane] = acc[i][j][e];
+    }
+    __syncthreads();
+    if (wk > 0) return;
+#pragma unroll
+    for (int q = 0; q < WK - 1; ++q)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            acc[i][j][e] += red[((q * WM * WN + wm * WN + wn) * TM * TN + i * TN + j) * 1024 + e * 64 + lane];
+  }
+
+  // epilogue: C/D map of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+  float* __restrict__ Y = a.Y + z * a.sY;
+  const float* __restrict__ bias = a.bias ? a.bias + z * a.sB : nullptr;
+  const float* __restrict__ res = a.res ? a.res + z * a.sR : nullptr;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + (wn * TN + j) * 32 + r;
+    if (col >= a.N) continue;
+    const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int rbase = m0 + (wm * TM + i) * 32 + 4 * h;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = rbase + (e & 3) + 8 * (e >> 2);
+        if (row < a.M) {
+          float v = acc[i][j][e] + bv;
+          if (a.act == ACT_GELU) v = gelu_erf(v);
+          if (res) {
+            int rr = row;
+            if (a.res_div != 1) rr /= a.res_div;
+            if (a.res_mod != 0x7fffffff) rr %= a.res_mod;
+            v += a.res_scale * res[(long long)rr * a.ldres + col];
+          }
+          Y[(long long)row * a.ldy + col] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN, int WK, int BK>
+static int launch(const GemmDev& d, int batch, hipStream_t stream) {
+  dim3 grid((d.N + BN - 1) / BN, (d.M + BM - 1) / BM, batch);
+  hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, WK, BK>), grid, dim3(WM * WN * WK * 64), 0, stream, d);
+  return check_launch("gemm_f32");
+}
+
+int gemm(const GemmArgs& a, hipStream_t stream) {
+  LBM_REQUIRE(a.M >= 0 && a.N > 0 && a.K > 0, "gemm: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
+  if (a.M == 0) return 0;
+  LBM_REQUIRE(a.K % 32 == 0, "gemm: K=%d must be a multiple of 32", a.K);
+  LBM_REQUIRE(a.ldx % 4 == 0 && a.ldw % 4 == 0, "gemm: ldx=%d / ldw=%d must be multiples of 4", a.ldx, a.ldw);
+  LBM_REQUIRE(a.ldx >= a.K && a.ldw >= a.K && a.ldy >= a.N, "gemm: leading dims too small");
+  LBM_REQUIRE(((uintptr_t)a.X & 15) == 0 && ((uintptr_t)a.W & 15) == 0, "gemm: X/W must be 16-byte aligned");
+  LBM_REQUIRE(a.sX % 4 == 0 && a.sW % 4 == 0, "gemm: batch strides must keep 16-byte alignment");
+  LBM_REQUIRE(a.res == nullptr || (a.res_div >= 1 && a.res_mod >= 1 && a.ldres >= a.N), "gemm: bad residual spec");
+  LBM_REQUIRE(a.batch >= 1 && a.batch <= 65535, "gemm: batch=%d out of range", a.batch);
+  const bool ln = a.ln_gamma != nullptr;
+  if (ln) LBM_REQUIRE(a.N == LBM_C && a.batch == 1 && a.ldy == LBM_C, "gemm: fused LayerNorm needs N == 256, ldy == 256");
+
+  GemmDev d{a.X, a.W, a.bias, a.Y, a.res, a.M, a.N, a.K, a.ldx, a.ldw, a.ldy, a.ldres,
+            a.res_div, a.res_mod, a.res_scale, a.act, a.sX, a.sW, a.sB, a.sY, a.sR};
+  const long long big = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.batch;
+  const long long mid = (long long)((a.M + 63) / 64) * ((a.N + 63) / 64) * a.batch;
+  int rc;
+  if (big >= 192)
+    rc = launch<128, 128, 2, 2, 1, 16>(d, a.batch, stream);
+  else if (mid >= 192)
+    rc = launch<64, 64, 2, 2, 1, 32>(d, a.batch, stream);
+  else
+    rc = launch<32, 32, 1, 1, 4, 32>(d, a.batch, stream);
+  if (rc) return rc;
+  if (ln) return layernorm_rows(a.Y, a.ln_gamma, a.ln_beta, a.Y, a.M, a.keep, a.fallback, a.Yn, stream);
+  return 0;
+}
+
+}  // namespace lbm

@@ -1,0 +1,252 @@
+// Feature pyramid, correlation maps and top-k selection.
+//
+//  * pyramid_pool   — transformer.py:58-69: levels 1..3 = avg_pool2d(level 0, 2/4/8), token-major.
+//  * corr_maps      — transformer.py:207-227 restructured.  The reference normalises every level,
+//                     takes q̂·f̂_l on each level, bilinearly upsamples the four *score* maps and mixes
+//                     them with a 1x1 conv plus the level-0 residual.  All of that is linear in f̂, so
+//                       corr[n, p] = q̂_n · F[p] + b,   F[p] = (1 + w0) f̂_0[p] + Σ_{l=1..3} w_l · up_l(f̂_l)[p]
+//                     and F (one (P,256) map per layer and stream, independent of the points) is built
+//                     here once per frame.  The (N, 4, h, w) score stack of the reference — 45 % of its
+//                     CPU time — never exists.
+//  * topk_rows      — transformer.py:307-308 + coord_utils.py:4-29: top-k cells of each correlation row
+//                     (ties → lowest index) and their cell centres in network pixels.
+#include "pyramid.hpp"
+
+namespace lbm {
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pyramid_pool_kernel(float* __restrict__ tok, int B, int h, int w, int L) {
+  // one 64-lane group per output cell (levels 1..3); lane owns 4 channels
+  const int lane = threadIdx.x & 63;
+  const int P0 = h * w;
+  const int per_stream = L - P0;
+  const long long total = (long long)B * per_stream;
+  for (long long cell = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); cell < total; cell += (long long)gridDim.x * 4) {
+    const int b = (int)(cell / per_stream);
+    int o = (int)(cell % per_stream);
+    int lvl = 1, start = P0;
+    int hl = h >> 1, wl = w >> 1;
+    while (o >= hl * wl) {
+      o -= hl * wl;
+      start += hl * wl;
+      ++lvl;
+      hl >>= 1;
+      wl >>= 1;
+    }
+    const int s = 1 << lvl;
+    const int y = o / wl, x = o % wl;
+    const float* src = tok + (long long)b * L * LBM_C + lane * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int dy = 0; dy < s; ++dy)
+      for (int dx = 0; dx < s; ++dx) {
+        const float4 v = ld4(src + (long long)((y * s + dy) * w + x * s + dx) * LBM_C);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+    const float inv = 1.0f / (float)(s * s);
+    st4(tok + ((long long)b * L + start + o) * LBM_C + lane * 4, make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv));
+  }
+}
+
+int pyramid_pool(float* tokens, int B, int h, int w, hipStream_t stream) {
+  LBM_REQUIRE(tokens && B > 0 && h % 8 == 0 && w % 8 == 0, "pyramid_pool: grid %dx%d must be a multiple of 8", h, w);
+  const int P0 = h * w;
+  const int L = P0 + P0 / 4 + P0 / 16 + P0 / 64;
+  long long blocks = ((long long)B * (L - P0) + 3) / 4;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(pyramid_pool_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, tokens, B, h, w, L);
+  return check_launch("pyramid_pool");
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void inv_norm_kernel(const float* __restrict__ tok, float* __restrict__ inv, long long rows) {
+  const int lane = threadIdx.x & 63;
+  for (long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long long)gridDim.x * 4) {
+    const float4 x = ld4(tok + row * LBM_C + lane * 4);
+    const float n = sqrtf(wave_sum(x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w));
+    if (lane == 0) inv[row] = 1.0f / fmaxf(n, 1e-12f);     // F.normalize eps
+  }
+}
+
+struct CorrMapArgs {
+  const float* tok;     // [B, L, 256]
+  const float* inv;     // [B, L]
+  float* F;             // [n_layers, B, P0, 256]
+  float wmix[8][4];     // per layer: corr_conv weights (w0..w3); the +1 residual is added here
+  int n_layers, B, h, w, L;
+};
+
+// bilinear source index/weights of F.interpolate(align_corners=False) from size `in` to `in << lvl`
+__device__ __forceinline__ void up_coeff(int dst, int lvl, int in, int& i0, int& i1, float& l0, float& l1) {
+  const float scale = 1.0f / (float)(1 << lvl);
+  float src = scale * ((float)dst + 0.5f) - 0.5f;
+  if (src < 0.f) src = 0.f;
+  i0 = (int)src;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+  l0 = 1.0f - l1;
+}
+
+__global__ __launch_bounds__(256) void corr_maps_kernel(CorrMapArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int P0 = a.h * a.w;
+  const long long total = (long long)a.B * P0;
+  for (long long cell = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); cell < total; cell += (long long)gridDim.x * 4) {
+    const int b = (int)(cell / P0);
+    const int p = (int)(cell % P0);
+    const int y = p / a.w, x = p % a.w;
+    const float* tb = a.tok + (long long)b * a.L * LBM_C + lane * 4;
+    const float* ib = a.inv + (long long)b * a.L;
+    float4 lv[4];
+    {
+      const float s = ib[p];
+      const float4 v = ld4(tb + (long long)p * LBM_C);
+      lv[0] = make_float4(v.x * s, v.y * s, v.z * s, v.w * s);
+    }
+    int start = P0;
+#pragma unroll
+    for (int l = 1; l < 4; ++l) {
+      const int hl = a.h >> l, wl = a.w >> l;
+      int y0, y1, x0, x1;
+      float ly0, ly1, lx0, lx1;
+      up_coeff(y, l, hl, y0, y1, ly0, ly1);
+      up_coeff(x, l, wl, x0, x1, lx0, lx1);
+      const int t00 = start + y0 * wl + x0, t01 = start + y0 * wl + x1;
+      const int t10 = start + y1 * wl + x0, t11 = start + y1 * wl + x1;
+      const float s00 = ib[t00], s01 = ib[t01], s10 = ib[t10], s11 = ib[t11];
+      const float4 v00 = ld4(tb + (long long)t00 * LBM_C), v01 = ld4(tb + (long long)t01 * LBM_C);
+      const float4 v10 = ld4(tb + (long long)t10 * LBM_C), v11 = ld4(tb + (long long)t11 * LBM_C);
+      float4 r;
+      r.x = ly0 * (lx0 * (v00.x * s00) + lx1 * (v01.x * s01)) + ly1 * (lx0 * (v10.x * s10) + lx1 * (v11.x * s11));
+      r.y = ly0 * (lx0 * (v00.y * s00) + lx1 * (v01.y * s01)) + ly1 * (lx0 * (v10.y * s10) + lx1 * (v11.y * s11));
+      r.z = ly0 * (lx0 * (v00.z * s00) + lx1 * (v01.z * s01)) + ly1 * (lx0 * (v10.z * s10) + lx1 * (v11.z * s11));
+      r.w = ly0 * (lx0 * (v00.w * s00) + lx1 * (v01.w * s01)) + ly1 * (lx0 * (v10.w * s10) + lx1 * (v11.w * s11));
+      lv[l] = r;
+      start += hl * wl;
+    }
+    for (int i = 0; i < a.n_layers; ++i) {
+      const float w0 = a.wmix[i][0] + 1.0f, w1 = a.wmix[i][1], w2 = a.wmix[i][2], w3 = a.wmix[i][3];
+      float4 o;
+      o.x = w0 * lv[0].x + w1 * lv[1].x + w2 * lv[2].x + w3 * lv[3].x;
+      o.y = w0 * lv[0].y + w1 * lv[1].y + w2 * lv[2].y + w3 * lv[3].y;
+      o.z = w0 * lv[0].z + w1 * lv[1].z + w2 * lv[2].z + w3 * lv[3].z;
+      o.w = w0 * lv[0].w + w1 * lv[1].w + w2 * lv[2].w + w3 * lv[3].w;
+      st4(a.F + (((long long)i * a.B + b) * P0 + p) * LBM_C + lane * 4, o);
+    }
+  }
+}
+
+int corr_maps(const float* tokens, float* inv_norm, float* F, const float* wmix_host, int n_layers, int B, int h, int w,
+              hipStream_t stream) {
+  LBM_REQUIRE(tokens && inv_norm && F && wmix_host, "corr_maps: null argument");
+  LBM_REQUIRE(n_layers >= 1 && n_layers <= 8, "corr_maps: n_layers=%d out of range", n_layers);
+  LBM_REQUIRE(B > 0 && h % 8 == 0 && w % 8 == 0, "corr_maps: grid %dx%d must be a multiple of 8", h, w);
+  const int P0 = h * w;
+  const int L = P0 + P0 / 4 + P0 / 16 + P0 / 64;
+  long long rows = (long long)B * L;
+  long long blocks = (rows + 3) / 4;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(inv_norm_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, tokens, inv_norm, rows);
+  if (check_launch("inv_norm")) return -1;
+  CorrMapArgs a;
+  a.tok = tokens; a.inv = inv_norm; a.F = F; a.n_layers = n_layers; a.B = B; a.h = h; a.w = w; a.L = L;
+  for (int i = 0; i < 8; ++i)
+    for (int l = 0; l < 4; ++l) a.wmix[i][l] = i < n_layers ? wmix_host[i * 4 + l] : 0.f;
+  blocks = ((long long)B * P0 + 3) / 4;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(corr_maps_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+  return check_launch("corr_maps");
+}
+
+// ------------------------------------------------------------------------------------------------
+// top-k of each row: per-lane sorted candidate list (static registers), then K rounds of a wave arg-max.
+template <int KMAX>
+__global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict__ corr, long long ld, int P, int k, int rows,
+                                                       int grid_w, float cell, int* __restrict__ idx_out,
+                                                       float* __restrict__ ref_out, float* __restrict__ val_out) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float lv[KMAX];
+  int li[KMAX];
+#pragma unroll
+  for (int t = 0; t < KMAX; ++t) {
+    lv[t] = -INFINITY;
+    li[t] = 0x7fffffff;
+  }
+  const float* src = corr + (long long)row * ld;
+  auto offer = [&](float v, int i) {
+    if (v > lv[KMAX - 1]) {
+      lv[KMAX - 1] = v;
+      li[KMAX - 1] = i;
+#pragma unroll
+      for (int t = KMAX - 1; t > 0; --t) {
+        if (lv[t] > lv[t - 1]) {
+          const float tv = lv[t]; lv[t] = lv[t - 1]; lv[t - 1] = tv;
+          const int ti = li[t]; li[t] = li[t - 1]; li[t - 1] = ti;
+        }
+      }
+    }
+  };
+  const int nvec = P >> 2;
+  for (int f = lane; f < nvec; f += 64) {
+    const float4 v = ld4(src + f * 4);
+    offer(v.x, f * 4);
+    offer(v.y, f * 4 + 1);
+    offer(v.z, f * 4 + 2);
+    offer(v.w, f * 4 + 3);
+  }
+  for (int i = (nvec << 2) + lane; i < P; i += 64) offer(src[i], i);
+
+  for (int t = 0; t < k; ++t) {
+    float bv = lv[0];
+    int bi = li[0];
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+      const float ov = __shfl_xor(bv, s);
+      const int oi = __shfl_xor(bi, s);
+      if (ov > bv || (ov == bv && oi < bi)) {
+        bv = ov;
+        bi = oi;
+      }
+    }
+    if (li[0] == bi) {   // the winning lane pops its head
+#pragma unroll
+      for (int q = 0; q < KMAX - 1; ++q) {
+        lv[q] = lv[q + 1];
+        li[q] = li[q + 1];
+      }
+      lv[KMAX - 1] = -INFINITY;
+      li[KMAX - 1] = 0x7fffffff;
+    }
+    if (lane == 0) {
+      const long long o = (long long)row * k + t;
+      idx_out[o] = bi;
+      if (ref_out) {
+        ref_out[o * 2 + 0] = (float)(bi % grid_w) * cell + 0.5f * cell;   // coord_utils.py:20-21
+        ref_out[o * 2 + 1] = (float)(bi / grid_w) * cell + 0.5f * cell;
+      }
+      if (val_out) val_out[o] = bv;
+    }
+  }
+}
+
+int topk_rows(const float* corr, long long ld, int P, int k, int rows, int grid_w, int stride_px, int* idx_out,
+              float* ref_out, float* val_out, hipStream_t stream) {
+  if (rows == 0) return 0;
+  LBM_REQUIRE(corr && idx_out, "topk_rows: null argument");
+  LBM_REQUIRE(k >= 1 && k <= 16 && k <= P, "topk_rows: k=%d out of range", k);
+  LBM_REQUIRE(ld % 4 == 0 && ((uintptr_t)corr & 15) == 0, "topk_rows: rows must be 16-byte aligned");
+  dim3 grid((rows + 3) / 4), block(256);
+  const float cell = (float)stride_px;
+  if (k == 1)
+    hipLaunchKernelGGL(topk_rows_kernel<1>, grid, block, 0, stream, corr, ld, P, k, rows, grid_w, cell, idx_out, ref_out, val_out);
+  else if (k <= 4)
+    hipLaunchKernelGGL(topk_rows_kernel<4>, grid, block, 0, stream, corr, ld, P, k, rows, grid_w, cell, idx_out, ref_out, val_out);
+  else if (k <= 9)
+    hipLaunchKernelGGL(topk_rows_kernel<9>, grid, block, 0, stream, corr, ld, P, k, rows, grid_w, cell, idx_out, ref_out, val_out);
+  else
+    hipLaunchKernelGGL(topk_rows_kernel<16>, grid, block, 0, stream, corr, ld, P, k, rows, grid_w, cell, idx_out, ref_out, val_out);
+  return check_launch("topk_rows");
+}
+
+}  // namespace lbm

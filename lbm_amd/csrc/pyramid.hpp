@@ -1,0 +1,17 @@
+#pragma once
+#include "common.hpp"
+
+namespace lbm {
+
+// tokens [B, L, 256] with level 0 in rows [0, h*w); fills rows [h*w, L) (levels 1..3) in place.
+int pyramid_pool(float* tokens, int B, int h, int w, hipStream_t stream);
+
+// inv_norm [B, L] scratch; F [n_layers, B, h*w, 256]; wmix_host = n_layers x 4 corr_conv weights (host memory).
+int corr_maps(const float* tokens, float* inv_norm, float* F, const float* wmix_host, int n_layers, int B, int h, int w,
+              hipStream_t stream);
+
+// per row: indices of the k largest values (ties -> lowest index), optional cell centres (x, y) and values.
+int topk_rows(const float* corr, long long ld, int P, int k, int rows, int grid_w, int stride_px, int* idx_out,
+              float* ref_out, float* val_out, hipStream_t stream);
+
+}  // namespace lbm

@@ -1,0 +1,64 @@
+// One wave per 256-channel row; each lane owns 4 consecutive channels (16-byte accesses).
+#include "rows.hpp"
+
+namespace lbm {
+
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* X, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float* Y, int rows,
+                                                             const uint8_t* __restrict__ keep,
+                                                             const float* __restrict__ fallback, float* __restrict__ Yn) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const long long off = (long long)row * LBM_C + lane * 4;
+  float4 y;
+  if (keep != nullptr && keep[row] == 0) {
+    y = ld4(fallback + off);
+  } else {
+    const float4 x = ld4(X + off);
+    const float mean = wave_sum(x.x + x.y + x.z + x.w) * (1.0f / LBM_C);
+    const float dx = x.x - mean, dy = x.y - mean, dz = x.z - mean, dw = x.w - mean;
+    const float var = wave_sum(dx * dx + dy * dy + dz * dz + dw * dw) * (1.0f / LBM_C);
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    const float4 g = ld4(gamma + lane * 4), b = ld4(beta + lane * 4);
+    y = make_float4(dx * rstd * g.x + b.x, dy * rstd * g.y + b.y, dz * rstd * g.z + b.z, dw * rstd * g.w + b.w);
+  }
+  st4(Y + off, y);
+  if (Yn != nullptr) {
+    const float n = sqrtf(wave_sum(y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w));
+    const float inv = 1.0f / fmaxf(n, 1e-12f);
+    st4(Yn + off, make_float4(y.x * inv, y.y * inv, y.z * inv, y.w * inv));
+  }
+}
+
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restrict__ X, long long ldx, float* __restrict__ Y,
+                                                          long long ldy, long long rows) {
+  const int lane = threadIdx.x & 63;
+  for (long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long long)gridDim.x * 4) {
+    const float4 x = ld4(X + row * ldx + lane * 4);
+    const float n = sqrtf(wave_sum(x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w));
+    const float inv = 1.0f / fmaxf(n, 1e-12f);
+    st4(Y + row * ldy + lane * 4, make_float4(x.x * inv, x.y * inv, x.z * inv, x.w * inv));
+  }
+}
+
+int layernorm_rows(const float* X, const float* gamma, const float* beta, float* Y, int rows, const uint8_t* keep,
+                   const float* fallback, float* Yn, hipStream_t stream) {
+  if (rows == 0) return 0;
+  LBM_REQUIRE(X && gamma && beta && Y && rows > 0, "layernorm_rows: null argument");
+  LBM_REQUIRE(keep == nullptr || fallback != nullptr, "layernorm_rows: keep mask needs a fallback");
+  hipLaunchKernelGGL(layernorm_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, X, gamma, beta, Y, rows, keep,
+                     fallback, Yn);
+  return check_launch("layernorm_rows");
+}
+
+int l2norm_rows(const float* X, long long ldx, float* Y, long long ldy, long long rows, hipStream_t stream) {
+  if (rows == 0) return 0;
+  LBM_REQUIRE(X && Y && ldx % 4 == 0 && ldy % 4 == 0, "l2norm_rows: bad arguments");
+  long long blocks = (rows + 3) / 4;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(l2norm_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, X, ldx, Y, ldy, rows);
+  return check_launch("l2norm_rows");
+}
+
+}  // namespace lbm

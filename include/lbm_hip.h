@@ -100,12 +100,25 @@ int lbm_hip_msda_sample(const lbm_hip_msda_desc* d, lbm_stream_t stream);
  * Encoder side.  preprocess: backbone.py:181-183; upcat: backbone.py:57-62 (pixel-major 64-channel
  * maps -> [B*h*w, 192]); sample_queries: lbm_online.py:72-81 / backbone.py:88-92.               */
 int lbm_hip_preprocess(const float* frames, int64_t frame_bstride, float* out, int32_t B, int32_t H, int32_t W,
-                       int32_t oh, int32_t ow, lbm_stream_t stream);
+                       int32_t oh, int32_t ow, int32_t out_nhwc /* 0: [B,3,oh,ow]; 3 or 4: [B,oh,ow,c], channel 3 zero */,
+                       lbm_stream_t stream);
 int lbm_hip_upcat(const float* p1, const float* p2, const float* p3, float* out, int32_t B, int32_t h, int32_t w,
                   lbm_stream_t stream);
 int lbm_hip_sample_queries(const float* tokens, int64_t tok_bstride, int32_t ld, const float* pts, float* out,
                            int32_t B, int32_t N, int32_t h, int32_t w, int32_t net_h, int32_t net_w,
                            lbm_stream_t stream);
+
+/* ResNet-18 body (backbone.py:20-26, 49-51; torchvision BasicBlock) on pixel-major activations:
+ * Y[b,oy,ox,:] = relu?(conv(X)[...] + bias (+ res)), BatchNorm folded into W/bias by the caller.
+ * X [B,H,W,Cin] with Cin a power of two >= 4 (the RGB stem is padded to 4 channels); W [Cout, ldw] with
+ * columns ordered (ky, kx, ci) and zero-padded to a multiple of 32 (ldw = 0 selects exactly that);
+ * `reserved` must be NULL.  maxpool: 3x3 / stride 2 / pad 1 (backbone.py:23).                    */
+int lbm_hip_conv2d_nhwc(const float* X, const float* W, const float* bias, const float* res, float* Y,
+                        const void* reserved, int32_t B, int32_t H, int32_t Wd, int32_t Cin, int32_t Cout,
+                        int32_t kh, int32_t kw, int32_t stride, int32_t pad, int32_t relu, int32_t ldw,
+                        lbm_stream_t stream);
+int lbm_hip_maxpool3x3s2_nhwc(const float* x, float* y, int32_t B, int32_t H, int32_t W, int32_t C,
+                              lbm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Whole tracking step = LBMTransformer.forward (transformer.py:74-151) + the state roll and output

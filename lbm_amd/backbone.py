@@ -16,6 +16,7 @@ import torch
 import torch.nn as nn
 
 from . import hip
+from . import engine
 
 
 class _BasicBlock(nn.Module):
@@ -60,7 +61,7 @@ class Backbone(nn.Module):
         self.P = self.H_prime * self.W_prime
         self.frame_pos_embedding = nn.Parameter(torch.zeros(1, embed_dim, self.H_prime, self.W_prime))
         nn.init.trunc_normal_(self.frame_pos_embedding, std=0.02)
-        self._packed = None          # hip.EncoderWeights, rebuilt when parameters change
+        self._packed = None          # engine.EncoderWeights, rebuilt when parameters change
 
     # -- weight packing -------------------------------------------------------------------------
     def _apply(self, fn, *a, **k):
@@ -71,9 +72,9 @@ class Backbone(nn.Module):
         self._packed = None
         return super().load_state_dict(*a, **k)
 
-    def packed(self) -> "hip.EncoderWeights":
+    def packed(self) -> "engine.EncoderWeights":
         if self._packed is None:
-            self._packed = hip.EncoderWeights(self)
+            self._packed = engine.EncoderWeights(self)
         return self._packed
 
     # -- reference API --------------------------------------------------------------------------

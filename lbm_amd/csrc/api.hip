@@ -328,8 +328,8 @@ int lbm_hip_msda_sample(const lbm_hip_msda_desc* d, lbm_stream_t stream) {
 }
 
 int lbm_hip_preprocess(const float* frames, int64_t frame_bstride, float* out, int32_t B, int32_t H, int32_t W, int32_t oh,
-                       int32_t ow, lbm_stream_t stream) {
-  return preprocess(frames, frame_bstride, out, B, H, W, oh, ow, (hipStream_t)stream);
+                       int32_t ow, int32_t out_nhwc, lbm_stream_t stream) {
+  return preprocess(frames, frame_bstride, out, B, H, W, oh, ow, out_nhwc, (hipStream_t)stream);
 }
 
 int lbm_hip_upcat(const float* p1, const float* p2, const float* p3, float* out, int32_t B, int32_t h, int32_t w,
@@ -340,6 +340,21 @@ int lbm_hip_upcat(const float* p1, const float* p2, const float* p3, float* out,
 int lbm_hip_sample_queries(const float* tokens, int64_t tok_bstride, int32_t ld, const float* pts, float* out, int32_t B,
                            int32_t N, int32_t h, int32_t w, int32_t net_h, int32_t net_w, lbm_stream_t stream) {
   return sample_queries(tokens, tok_bstride, ld, pts, out, B, N, h, w, net_h, net_w, (hipStream_t)stream);
+}
+
+int lbm_hip_conv2d_nhwc(const float* X, const float* W, const float* bias, const float* res, float* Y, const void* reserved,
+                        int32_t B, int32_t H, int32_t Wd, int32_t Cin, int32_t Cout, int32_t kh, int32_t kw, int32_t stride,
+                        int32_t pad, int32_t relu, int32_t ldw, lbm_stream_t stream) {
+  (void)reserved;
+  ConvArgs c;
+  c.X = X; c.W = W; c.bias = bias; c.res = res; c.Y = Y;
+  c.B = B; c.H = H; c.Wd = Wd; c.Cin = Cin; c.Cout = Cout; c.kh = kh; c.kw = kw; c.stride = stride; c.pad = pad; c.relu = relu;
+  c.ldw = ldw > 0 ? ldw : (kh * kw * Cin + 31) / 32 * 32;
+  return conv2d_nhwc(c, (hipStream_t)stream);
+}
+
+int lbm_hip_maxpool3x3s2_nhwc(const float* x, float* y, int32_t B, int32_t H, int32_t W, int32_t C, lbm_stream_t stream) {
+  return maxpool3x3s2_nhwc(x, y, B, H, W, C, (hipStream_t)stream);
 }
 
 uint64_t lbm_hip_step_workspace_bytes(const lbm_hip_step_desc* d) {

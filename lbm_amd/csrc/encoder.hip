@@ -16,7 +16,7 @@ __device__ __forceinline__ void resize_coeff(int dst, float scale, int in, int& 
 
 // backbone.py:181-183: x/255 -> bilinear resize (no antialias) -> (x - mean)/std.   NCHW in, NCHW out.
 __global__ __launch_bounds__(256) void preprocess_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H,
-                                                         int W, int oh, int ow, long long in_bstride) {
+                                                         int W, int oh, int ow, long long in_bstride, int out_nhwc) {
   const float sy = (float)H / (float)oh, sx = (float)W / (float)ow;
   const long long total = (long long)B * 3 * oh * ow;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -34,15 +34,20 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const float* __restrict
     const float v = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
     const float mean = c == 0 ? 0.485f : (c == 1 ? 0.456f : 0.406f);
     const float sd = c == 0 ? 0.229f : (c == 1 ? 0.224f : 0.225f);
-    out[i] = (v - mean) / sd;
+    // out_nhwc: 0 = [B,3,oh,ow]; 3 or 4 = pixel-major with that many channels (channel 3 zero-filled)
+    const long long o = out_nhwc ? (((long long)b * oh + y) * ow + x) * out_nhwc + c : i;
+    out[o] = (v - mean) / sd;
+    if (out_nhwc == 4 && c == 0) out[o + 3] = 0.f;
   }
 }
 
-int preprocess(const float* frames, long long frame_bstride, float* out, int B, int H, int W, int oh, int ow, hipStream_t stream) {
+int preprocess(const float* frames, long long frame_bstride, float* out, int B, int H, int W, int oh, int ow, int out_nhwc,
+               hipStream_t stream) {
   LBM_REQUIRE(frames && out && B > 0 && H > 0 && W > 0 && oh > 0 && ow > 0, "preprocess: bad arguments");
+  LBM_REQUIRE(out_nhwc == 0 || out_nhwc == 3 || out_nhwc == 4, "preprocess: out_nhwc must be 0, 3 or 4");
   long long blocks = ((long long)B * 3 * oh * ow + 255) / 256;
   if (blocks > 65535) blocks = 65535;
-  hipLaunchKernelGGL(preprocess_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, frames, out, B, H, W, oh, ow, frame_bstride);
+  hipLaunchKernelGGL(preprocess_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, frames, out, B, H, W, oh, ow, frame_bstride, out_nhwc);
   return check_launch("preprocess");
 }
 

@@ -4,7 +4,7 @@
 
 namespace lbm {
 
-enum Act { ACT_NONE = 0, ACT_GELU = 1 };
+enum Act { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU_POST = 2 };  // RELU_POST: relu(acc + bias + res)
 
 struct GemmArgs {
   const float* X = nullptr;   // [M, K] row-major, leading dim ldx
@@ -29,5 +29,17 @@ struct GemmArgs {
 };
 
 int gemm(const GemmArgs& a, hipStream_t stream);
+
+// NHWC convolution as an implicit GEMM: Y[b,oy,ox,:] = relu?( sum W[:, (ky,kx,ci)] * X[b, oy*s-p+ky, ox*s-p+kx, ci] + bias (+ res) )
+struct ConvArgs {
+  const float* X = nullptr;     // [B, H, Wd, Cin], Cin a power of two >= 4
+  const float* W = nullptr;     // [Cout, ldw], row = (ky, kx, ci) tap-major, zero-padded to a multiple of 32 columns
+  const float* bias = nullptr;  // [Cout] (folded BatchNorm shift) or null
+  const float* res = nullptr;   // optional [B, Ho, Wo, Cout] residual added before the ReLU
+  float* Y = nullptr;           // [B, Ho, Wo, Cout]
+  int B = 0, H = 0, Wd = 0, Cin = 0, Cout = 0, kh = 0, kw = 0, stride = 1, pad = 0, relu = 0, ldw = 0;
+};
+int conv2d_nhwc(const ConvArgs& c, hipStream_t stream);
+int maxpool3x3s2_nhwc(const float* x, float* y, int B, int H, int W, int C, hipStream_t stream);
 
 }  // namespace lbm

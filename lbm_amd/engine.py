@@ -1,0 +1,342 @@
+"""Host side of the tracking step: weight folding/packing and the call into ``lbm_hip_track_step``.
+
+* :class:`EncoderWeights` — BatchNorm folded into the ResNet-18 convolutions (backbone.py:20-26),
+  tap-major NHWC weight packing, the fused 1x1 fusion conv (backbone.py:33-37, 53-65).
+* :class:`TrackerWeights` — the LBM_W_* table of ``include/lbm_hip.h``: for every nn.MultiheadAttention
+  of the reference (transformer.py:161,169,185) the query/key projections are folded into one
+  ``[1024,256]`` matrix per block (per head ``Wk_hᵀ Wq_h / sqrt(64)``) and the value/output projections into
+  one ``[256,1024]`` matrix, so the kernels never project the M memory slots; the "now" time embedding
+  (transformer.py:268,290) is folded into the two biases.
+* :class:`TrackEngine` — owns the workspace and fills the step descriptor.
+
+Folding is done once, in float64 on the host, and rounded to fp32.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import hip
+from .config import LBMConfig
+
+
+def _f64(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().to("cpu", torch.float64)
+
+
+# ----------------------------------------------------------------------------------------------
+# encoder
+# ----------------------------------------------------------------------------------------------
+
+def _fold_bn(conv_w: torch.Tensor, bn) -> (torch.Tensor, torch.Tensor):
+    """conv (no bias) followed by eval-mode BatchNorm -> (w', b')."""
+    scale = _f64(bn.weight) / torch.sqrt(_f64(bn.running_var) + bn.eps)
+    w = _f64(conv_w) * scale.view(-1, 1, 1, 1)
+    b = _f64(bn.bias) - _f64(bn.running_mean) * scale
+    return w, b
+
+
+def _pack_conv(w: torch.Tensor, cin_pad: int = 0) -> torch.Tensor:
+    """(Cout, Cin, kh, kw) -> (Cout, roundup32(kh*kw*Cin')) with columns ordered (ky, kx, ci)."""
+    Cout, Cin, kh, kw = w.shape
+    if cin_pad and cin_pad > Cin:
+        w = torch.cat([w, torch.zeros(Cout, cin_pad - Cin, kh, kw, dtype=w.dtype)], dim=1)
+        Cin = cin_pad
+    flat = w.permute(0, 2, 3, 1).reshape(Cout, kh * kw * Cin)
+    K = flat.shape[1]
+    Kp = (K + 31) // 32 * 32
+    if Kp != K:
+        flat = torch.cat([flat, torch.zeros(Cout, Kp - K, dtype=w.dtype)], dim=1)
+    return flat.contiguous()
+
+
+class _Conv:
+    def __init__(self, w, b, kh, stride, pad, dev):
+        self.w = w.to(dev, torch.float32).contiguous()
+        self.b = b.to(dev, torch.float32).contiguous()
+        self.kh, self.stride, self.pad = kh, stride, pad
+
+    def __call__(self, x, relu, res=None):
+        return hip.conv2d_nhwc(x, self.w, self.b, self.kh, self.kh, self.stride, self.pad, relu, res)
+
+
+class EncoderWeights:
+    def __init__(self, bb):
+        dev = bb.frame_pos_embedding.device
+        if dev.type != "cuda":
+            raise hip.HipError("the encoder runs on the GPU only: move the model with .cuda() first")
+        self.size = tuple(bb.size)
+        self.h, self.w = bb.H_prime, bb.W_prime
+        self.P0 = self.h * self.w
+        self.L = self.P0 + self.P0 // 4 + self.P0 // 16 + self.P0 // 64
+        self.dev = dev
+        w, b = _fold_bn(bb.layer1[0].weight, bb.layer1[1])
+        self.stem = _Conv(_pack_conv(w, 4), b, 7, 2, 3, dev)
+        self.blocks = []
+        for stage in (bb.layer1[4], bb.layer2, bb.layer3):
+            for blk in stage:
+                w1, b1 = _fold_bn(blk.conv1.weight, blk.bn1)
+                w2, b2 = _fold_bn(blk.conv2.weight, blk.bn2)
+                down = None
+                if blk.downsample is not None:
+                    wd, bd = _fold_bn(blk.downsample[0].weight, blk.downsample[1])
+                    down = _Conv(_pack_conv(wd), bd, 1, blk.stride, 0, dev)
+                self.blocks.append((_Conv(_pack_conv(w1), b1, 3, blk.stride, 1, dev), _Conv(_pack_conv(w2), b2, 3, 1, 1, dev), down))
+        f32 = lambda t: t.to(dev, torch.float32).contiguous()
+        self.proj = [(f32(_f64(p.weight).flatten(1)), f32(_f64(p.bias))) for p in (bb.proj1, bb.proj2, bb.proj3)]
+        fw, fb = _fold_bn(bb.fusion[0].weight, bb.fusion[1])
+        scale = _f64(bb.fusion[1].weight) / torch.sqrt(_f64(bb.fusion[1].running_var) + bb.fusion[1].eps)
+        fb = fb + _f64(bb.fusion[0].bias) * scale
+        self.fusion_w, self.fusion_b = f32(fw.flatten(1)), f32(fb)
+        # positional embedding, token-major (P0, 256)
+        self.pos = f32(_f64(bb.frame_pos_embedding)[0].permute(1, 2, 0).reshape(self.P0, -1))
+
+    def encode(self, frames: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        x = hip.preprocess(frames, self.size[0], self.size[1], layout=4)
+        return self._body(x, True, out)
+
+    def encode_normalised(self, x_nchw: torch.Tensor, add_pos: bool = True) -> torch.Tensor:
+        B = x_nchw.shape[0]
+        x = torch.zeros(B, self.size[0], self.size[1], 4, device=self.dev)
+        x[..., :3] = x_nchw.permute(0, 2, 3, 1)
+        return self._body(x, add_pos, None)
+
+    def _body(self, x: torch.Tensor, add_pos: bool, out: Optional[torch.Tensor]) -> torch.Tensor:
+        B = x.shape[0]
+        y = self.stem(x, True)
+        y = hip.maxpool3x3s2_nhwc(y)
+        feats = []
+        for i, (c1, c2, down) in enumerate(self.blocks):
+            idn = y if down is None else down(y, False)
+            t = c1(y, True)
+            y = c2(t, True, idn)
+            if i % 2 == 1:
+                feats.append(y)
+        ps = []
+        for f, (pw, pb) in zip(feats, self.proj):
+            ps.append(hip.linear(f.view(-1, f.shape[-1]), pw, pb))
+        cat = hip.upcat(ps[0], ps[1], ps[2], B, self.h, self.w)
+        if out is None:
+            out = torch.empty(B, self.L, 256, device=self.dev, dtype=torch.float32)
+        hip.linear_batched(cat, self.fusion_w, out, bias=self.fusion_b, act=1, res=self.pos if add_pos else None,
+                           strides=(self.P0 * 192, 0, 0, self.L * 256, 0), M=self.P0, N=256, K=192, ldx=192, ldw=192,
+                           ldy=256, ldres=256, batch=B)
+        hip.pyramid(out, self.h, self.w)
+        return out
+
+
+# ----------------------------------------------------------------------------------------------
+# tracker transformer
+# ----------------------------------------------------------------------------------------------
+
+def fold_attention(mha, e_now: Optional[torch.Tensor], n_head: int = 4):
+    """nn.MultiheadAttention parameters -> (G [4C,C], gb [4C], Hm [C,4C], hb [C]) in float64.
+
+    u_h = G_h x + gb_h reproduces Wk_hᵀ(Wq_h (x + e_now) + bq_h)/sqrt(d); out = Hm · concat_h(m̄_h) + hb
+    reproduces out_proj(concat_h(Wv_h m̄_h + bv_h)) + e_now (the residual carries x + e_now)."""
+    Wi, bi = _f64(mha.in_proj_weight), _f64(mha.in_proj_bias)
+    Wo, bo = _f64(mha.out_proj.weight), _f64(mha.out_proj.bias)
+    Cc = Wo.shape[0]
+    d = Cc // n_head
+    Wq, Wk, Wv = Wi[:Cc], Wi[Cc:2 * Cc], Wi[2 * Cc:]
+    bq, bv = bi[:Cc], bi[2 * Cc:]
+    e = torch.zeros(Cc, dtype=torch.float64) if e_now is None else _f64(e_now).reshape(Cc)
+    G, gb, Hm = [], [], []
+    for h in range(n_head):
+        sl = slice(h * d, (h + 1) * d)
+        Gh = Wk[sl].t() @ Wq[sl] / (d ** 0.5)
+        G.append(Gh)
+        gb.append(Gh @ e + Wk[sl].t() @ bq[sl] / (d ** 0.5))
+        Hm.append(Wo[:, sl] @ Wv[sl])
+    hb = Wo @ bv + bo + e
+    return torch.cat(G, 0), torch.cat(gb, 0), torch.cat(Hm, 1), hb
+
+
+class TrackerWeights:
+    """Device-resident LBM_W_* pointer table for one LBMTransformer (keeps the packed tensors alive)."""
+
+    def __init__(self, tr, cfg: LBMConfig):
+        cfg.validate_for_hip()
+        self.cfg = cfg
+        k = hip.header_constants()
+        dev = tr.spatial_shapes.device
+        if dev.type != "cuda":
+            raise hip.HipError("the tracker runs on the GPU only: move the model with .cuda() first")
+        n_layers = len(tr.layers)
+        n = n_layers * k["LBM_W_LAYER_COUNT"] + k["LBM_W_HEAD_COUNT"]
+        self.tensors: List[Optional[torch.Tensor]] = [None] * n
+        self.memory_size = tr.layers[0].collision_time_emb.shape[1] - 1
+
+        def put(idx, t):
+            self.tensors[idx] = t.detach().to(dev, torch.float32).contiguous()
+
+        def put_attn(base, mha, temb, ln1, ffn, ln2):
+            e_now = None if temb is None else temb[0, -1]
+            G, gb, Hm, hb = fold_attention(mha, e_now, cfg.num_heads)
+            put(base + k["LBM_W_ATTN_G"], G)
+            put(base + k["LBM_W_ATTN_GB"], gb)
+            if temb is not None:
+                put(base + k["LBM_W_ATTN_TEMB"], temb[0, :-1])
+            put(base + k["LBM_W_ATTN_HM"], Hm)
+            put(base + k["LBM_W_ATTN_HB"], hb)
+            put(base + k["LBM_W_ATTN_LN1G"], ln1.weight)
+            put(base + k["LBM_W_ATTN_LN1B"], ln1.bias)
+            put(base + k["LBM_W_ATTN_F1W"], ffn.net[0].weight)
+            put(base + k["LBM_W_ATTN_F1B"], ffn.net[0].bias)
+            put(base + k["LBM_W_ATTN_F2W"], ffn.net[3].weight)
+            put(base + k["LBM_W_ATTN_F2B"], ffn.net[3].bias)
+            put(base + k["LBM_W_ATTN_LN2G"], ln2.weight)
+            put(base + k["LBM_W_ATTN_LN2B"], ln2.bias)
+
+        def put_msda(base, att, ln1, ffn, ln2):
+            put(base + k["LBM_W_MSDA_OLW"], torch.cat([att.sampling_offsets.weight, att.attention_weights.weight], 0))
+            put(base + k["LBM_W_MSDA_OLB"], torch.cat([att.sampling_offsets.bias, att.attention_weights.bias], 0))
+            put(base + k["LBM_W_MSDA_OUTW"], att.output_proj.weight)
+            put(base + k["LBM_W_MSDA_OUTB"], att.output_proj.bias)
+            put(base + k["LBM_W_MSDA_LN1G"], ln1.weight)
+            put(base + k["LBM_W_MSDA_LN1B"], ln1.bias)
+            put(base + k["LBM_W_MSDA_F1W"], ffn.net[0].weight)
+            put(base + k["LBM_W_MSDA_F1B"], ffn.net[0].bias)
+            put(base + k["LBM_W_MSDA_F2W"], ffn.net[3].weight)
+            put(base + k["LBM_W_MSDA_F2B"], ffn.net[3].bias)
+            put(base + k["LBM_W_MSDA_LN2G"], ln2.weight)
+            put(base + k["LBM_W_MSDA_LN2B"], ln2.bias)
+
+        self.corr_mix: List[float] = []
+        self.corr_bias: List[float] = []
+        vw, vb = [], []
+        for i, ly in enumerate(tr.layers):
+            base = i * k["LBM_W_LAYER_COUNT"]
+            put_attn(base + k["LBM_W_LAYER_COLL"], ly.collision_attention, ly.collision_time_emb, ly.collision_norm,
+                     ly.collision_ffn, ly.collision_norm2)
+            put_attn(base + k["LBM_W_LAYER_STREAM"], ly.stream_attention, ly.stream_time_emb, ly.stream_norm,
+                     ly.stream_ffn, ly.stream_norm2)
+            put_msda(base + k["LBM_W_LAYER_LATTICE"], ly.lattice_attention, ly.lattice_norm, ly.lattice_ffn, ly.lattice_norm2)
+            put_attn(base + k["LBM_W_LAYER_UPDATE"], ly.lattice_update, None, ly.lattice_update_norm,
+                     ly.lattice_update_ffn, ly.lattice_update_norm2)
+            put(base + k["LBM_W_LAYER_RHO_W"], ly.reference_rho.weight)
+            put(base + k["LBM_W_LAYER_RHO_B"], ly.reference_rho.bias)
+            self.corr_mix += [float(v) for v in ly.corr_conv.weight.detach().flatten().tolist()]
+            self.corr_bias.append(float(ly.corr_conv.bias.detach().item()))
+            vw.append(ly.lattice_attention.value_proj.weight)
+            vb.append(ly.lattice_attention.value_proj.bias)
+        hb_ = n_layers * k["LBM_W_LAYER_COUNT"]
+        put_msda(hb_ + k["LBM_W_HEAD_OFFSET"], tr.offset_layer, tr.offset_norm, tr.offset_ffn, tr.offset_norm2)
+        put_msda(hb_ + k["LBM_W_HEAD_CMEM"], tr.collision_mem_layer, tr.collision_mem_norm, tr.collision_mem_ffn,
+                 tr.collision_mem_norm2)
+        put_msda(hb_ + k["LBM_W_HEAD_VIS"], tr.vis_layer, tr.vis_norm, tr.vis_ffn, tr.vis_norm2)
+        for name, head in (("OFFH", tr.offset_head), ("VISH", tr.vis_head)):
+            put(hb_ + k[f"LBM_W_HEAD_{name}_W0"], head.net[0].weight)
+            put(hb_ + k[f"LBM_W_HEAD_{name}_B0"], head.net[0].bias)
+            put(hb_ + k[f"LBM_W_HEAD_{name}_W3"], head.net[3].weight)
+            put(hb_ + k[f"LBM_W_HEAD_{name}_B3"], head.net[3].bias)
+        for att in (tr.offset_layer, tr.collision_mem_layer, tr.vis_layer):
+            vw.append(att.value_proj.weight)
+            vb.append(att.value_proj.bias)
+        put(hb_ + k["LBM_W_HEAD_VPROJ_W"], torch.cat(vw, 0))
+        put(hb_ + k["LBM_W_HEAD_VPROJ_B"], torch.cat(vb, 0))
+        self.table = (C.c_void_p * n)(*[None if t is None else t.data_ptr() for t in self.tensors])
+        self.n = n
+        self.n_layers = n_layers
+        self.device = dev
+
+
+class TrackEngine:
+    """Fills ``lbm_hip_step_desc`` and enqueues one tracking step on the current stream."""
+
+    def __init__(self, cfg: LBMConfig, weights: TrackerWeights):
+        self.cfg = cfg
+        self.w = weights
+        self.dev = weights.device
+        self._ws: Optional[torch.Tensor] = None
+        self._ws_key = None
+
+    def _desc(self, B: int, N: int, M: int) -> hip.StepDesc:
+        cfg = self.cfg
+        d = hip.StepDesc()
+        d.B, d.N, d.M, d.n_layers = B, N, M, self.w.n_layers
+        for i, kk in enumerate(cfg.topk_per_layer):
+            d.topk[i] = kk
+        d.net_h, d.net_w, d.stride = cfg.input_size[0], cfg.input_size[1], cfg.stride
+        d.n_points, d.n_points_cmem = cfg.num_neighbors, 4
+        d.vis_threshold = 0.8
+        for i, v in enumerate(self.w.corr_mix):
+            d.corr_mix[i] = v
+        for i, v in enumerate(self.w.corr_bias):
+            d.corr_bias[i] = v
+        d.weights = C.cast(self.w.table, C.POINTER(C.c_void_p))
+        d.n_weights = self.w.n
+        return d
+
+    def workspace(self, d: hip.StepDesc) -> torch.Tensor:
+        key = (d.B, d.N, d.M)
+        if self._ws is None or self._ws_key != key:
+            nbytes = int(hip.load().lbm_hip_step_workspace_bytes(C.byref(d)))
+            if nbytes == 0:
+                raise hip.HipError("step workspace: " + hip.load().lbm_hip_last_error().decode())
+            self._ws = None
+            self._ws = torch.empty(nbytes, device=self.dev, dtype=torch.uint8)
+            self._ws_key = key
+        return self._ws
+
+    def step(self, tokens: torch.Tensor, query: torch.Tensor, stream_mem: torch.Tensor, coll_mem: torch.Tensor,
+             vis_mask: torch.Tensor, mem_mask: torch.Tensor, ring_head: int = 0, queried: Optional[torch.Tensor] = None,
+             update_state: bool = True, img_hw: Optional[Sequence[int]] = None, want_memory: bool = False,
+             want_aux: bool = False, want_corr: bool = False, vis_threshold: float = 0.8) -> Dict[str, torch.Tensor]:
+        """tokens (B,L,256) pyramid; query (B,N,256); memories (B,N,M,256) in ring order; masks (B,N,M) bool/uint8."""
+        hip._require_gpu()
+        if self.w.memory_size != stream_mem.shape[2]:
+            raise hip.HipError(f"memory has {stream_mem.shape[2]} slots but the time embeddings were built for "
+                               f"{self.w.memory_size}; call set_memory_size first")
+        B, N, M = stream_mem.shape[:3]
+        cfg = self.cfg
+        d = self._desc(B, N, M)
+        d.vis_threshold = vis_threshold
+        d.ring_head, d.update_state = ring_head, 1 if update_state else 0
+        ih, iw = img_hw if img_hw is not None else cfg.input_size
+        d.img_h, d.img_w = float(ih), float(iw)
+        ws = self.workspace(d)
+        dev = self.dev
+        out: Dict[str, torch.Tensor] = {
+            "coords": torch.empty(B, N, 2, device=dev), "vis": torch.empty(B, N, device=dev),
+            "rho": torch.empty(B, N, device=dev), "offset": torch.empty(B, N, 2, device=dev)}
+        if want_memory:
+            out["stream"] = torch.empty(B, N, 256, device=dev)
+            out["collision"] = torch.empty(B, N, 256, device=dev)
+            d.stream_out, d.coll_out = out["stream"].data_ptr(), out["collision"].data_ptr()
+        P0 = cfg.num_cells
+        for i, kk in enumerate(cfg.topk_per_layer):
+            last = i == len(cfg.topk_per_layer) - 1
+            if want_aux or last:
+                out[f"ref{i}"] = torch.empty(B, N, kk, 2, device=dev)
+                d.ref_points[i] = out[f"ref{i}"].data_ptr()
+            if want_aux:
+                out[f"idx{i}"] = torch.empty(B, N, kk, device=dev, dtype=torch.int32)
+                out[f"rho{i}"] = torch.empty(B, N, kk, device=dev)
+                d.topk_idx[i] = out[f"idx{i}"].data_ptr()
+                d.ref_rho[i] = out[f"rho{i}"].data_ptr()
+            if want_corr:
+                out[f"corr{i}"] = torch.empty(B, N, P0, device=dev)
+                d.corr[i] = out[f"corr{i}"].data_ptr()
+        d.tokens, d.query = hip._p(tokens), hip._p(query)
+        d.stream_mem, d.coll_mem = hip._p(stream_mem), hip._p(coll_mem)
+        d.vis_mask, d.mem_mask = hip._p(vis_mask, torch.uint8), hip._p(mem_mask, torch.uint8)
+        d.queried = hip._p(queried, torch.uint8)
+        d.coords, d.vis, d.rho, d.offset = (out[n].data_ptr() for n in ("coords", "vis", "rho", "offset"))
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+        hip._check(hip.load().lbm_hip_track_step(C.byref(d), hip._stream()), "lbm_hip_track_step")
+        if want_corr:   # the kernels rank without the (constant) bias; the returned map carries it
+            for i in range(len(cfg.topk_per_layer)):
+                out[f"corr{i}"] += self.w.corr_bias[i]
+        self._last_desc = d
+        return out
+
+    def debug_buffer(self, name: str, shape, dtype=torch.float32) -> torch.Tensor:
+        """View of a named workspace intermediate after a step (parity debugging)."""
+        off = int(hip.load().lbm_hip_step_workspace_offset(C.byref(self._last_desc), name.encode()))
+        if off < 0:
+            raise KeyError(name)
+        n = int(torch.tensor(shape).prod()) * torch.empty((), dtype=dtype).element_size()
+        return self._ws[off:off + n].view(dtype).view(*shape)

@@ -1,0 +1,372 @@
+"""ctypes binding of ``liblbm_hip.so`` (C ABI in ``include/lbm_hip.h``).
+
+PyTorch is used for device memory and streams only: every function here hands raw device pointers of
+caller-owned tensors to the HIP library and enqueues on ``torch.cuda.current_stream()``.  There is no
+PyTorch/CPU fallback — if the library is missing or no GPU is present the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+from pathlib import Path
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+_HERE = Path(__file__).resolve().parent
+_LIB_PATH = _HERE / "liblbm_hip.so"
+_HEADER = _HERE.parent / "include" / "lbm_hip.h"
+MAX_LAYERS = 8
+
+# every symbol include/lbm_hip.h declares (checked at load time and by the CPU tests)
+EXPORTS = (
+    "lbm_hip_version", "lbm_hip_last_error", "lbm_hip_linear", "lbm_hip_layernorm", "lbm_hip_l2norm",
+    "lbm_hip_attn_readout", "lbm_hip_pyramid", "lbm_hip_corr_maps", "lbm_hip_topk", "lbm_hip_msda_sample",
+    "lbm_hip_preprocess", "lbm_hip_upcat", "lbm_hip_sample_queries", "lbm_hip_step_workspace_bytes",
+    "lbm_hip_track_step", "lbm_hip_step_workspace_offset", "lbm_hip_conv2d_nhwc", "lbm_hip_maxpool3x3s2_nhwc",
+)
+
+
+class HipError(RuntimeError):
+    pass
+
+
+class LinearDesc(C.Structure):
+    _fields_ = [("X", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p), ("Y", C.c_void_p), ("res", C.c_void_p),
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("ldx", C.c_int32), ("ldw", C.c_int32),
+                ("ldy", C.c_int32), ("ldres", C.c_int32), ("res_div", C.c_int32), ("res_mod", C.c_int32),
+                ("res_scale", C.c_float), ("act", C.c_int32), ("batch", C.c_int32),
+                ("sX", C.c_int64), ("sW", C.c_int64), ("sB", C.c_int64), ("sY", C.c_int64), ("sR", C.c_int64),
+                ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("keep", C.c_void_p), ("fallback", C.c_void_p),
+                ("Yn", C.c_void_p)]
+
+
+class MsdaDesc(C.Structure):
+    _fields_ = [("value", C.c_void_p), ("v_batch_stride", C.c_int64), ("ldv", C.c_int32),
+                ("lvl_h", C.c_int32 * 4), ("lvl_w", C.c_int32 * 4), ("lvl_start", C.c_int32 * 4),
+                ("B", C.c_int32), ("N", C.c_int32), ("k", C.c_int32), ("P", C.c_int32),
+                ("offlog", C.c_void_p), ("ld_offlog", C.c_int32), ("logit_col", C.c_int32),
+                ("ref", C.c_void_p), ("net_w", C.c_float), ("net_h", C.c_float),
+                ("loc", C.c_void_p), ("attw", C.c_void_p), ("out", C.c_void_p)]
+
+
+class StepDesc(C.Structure):
+    _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("M", C.c_int32), ("n_layers", C.c_int32),
+                ("topk", C.c_int32 * MAX_LAYERS),
+                ("net_h", C.c_int32), ("net_w", C.c_int32), ("stride", C.c_int32),
+                ("n_points", C.c_int32), ("n_points_cmem", C.c_int32),
+                ("ring_head", C.c_int32), ("update_state", C.c_int32),
+                ("vis_threshold", C.c_float), ("img_h", C.c_float), ("img_w", C.c_float),
+                ("corr_mix", C.c_float * (MAX_LAYERS * 4)), ("corr_bias", C.c_float * MAX_LAYERS),
+                ("weights", C.POINTER(C.c_void_p)), ("n_weights", C.c_int32),
+                ("tokens", C.c_void_p), ("query", C.c_void_p), ("stream_mem", C.c_void_p), ("coll_mem", C.c_void_p),
+                ("vis_mask", C.c_void_p), ("mem_mask", C.c_void_p), ("queried", C.c_void_p),
+                ("coords", C.c_void_p), ("vis", C.c_void_p), ("rho", C.c_void_p), ("offset", C.c_void_p),
+                ("stream_out", C.c_void_p), ("coll_out", C.c_void_p),
+                ("ref_points", C.c_void_p * MAX_LAYERS), ("topk_idx", C.c_void_p * MAX_LAYERS),
+                ("ref_rho", C.c_void_p * MAX_LAYERS), ("corr", C.c_void_p * MAX_LAYERS),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_uint64)]
+
+
+_lib: Optional[C.CDLL] = None
+_consts: Optional[Dict[str, int]] = None
+
+
+def header_constants() -> Dict[str, int]:
+    """``#define LBM_* <int>`` values of include/lbm_hip.h (the weight-table layout lives there)."""
+    global _consts
+    if _consts is None:
+        text = _HEADER.read_text()
+        _consts = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+(LBM_\w+)\s+(\d+)\b", text)}
+    return _consts
+
+
+def lib_path() -> Path:
+    return _LIB_PATH
+
+
+def load() -> C.CDLL:
+    """Load the shared library (no GPU needed for loading); raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not _LIB_PATH.exists():
+        raise HipError(f"{_LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       f"or `make -C {_HERE / 'csrc'}`; lbm_amd has no fallback path")
+    lib = C.CDLL(str(_LIB_PATH))
+    for name in EXPORTS:
+        if not hasattr(lib, name):
+            raise HipError(f"{_LIB_PATH} does not export {name}")
+    lib.lbm_hip_last_error.restype = C.c_char_p
+    lib.lbm_hip_step_workspace_bytes.restype = C.c_uint64
+    lib.lbm_hip_step_workspace_offset.restype = C.c_int64
+    lib.lbm_hip_step_workspace_offset.argtypes = [C.POINTER(StepDesc), C.c_char_p]
+    lib.lbm_hip_linear.argtypes = [C.POINTER(LinearDesc), C.c_void_p]
+    lib.lbm_hip_layernorm.argtypes = [C.c_void_p] * 4 + [C.c_int32] + [C.c_void_p] * 4
+    lib.lbm_hip_l2norm.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+    lib.lbm_hip_attn_readout.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    lib.lbm_hip_pyramid.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    lib.lbm_hip_corr_maps.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_int32, C.c_int32,
+                                      C.c_int32, C.c_int32, C.c_void_p]
+    lib.lbm_hip_topk.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.lbm_hip_msda_sample.argtypes = [C.POINTER(MsdaDesc), C.c_void_p]
+    lib.lbm_hip_preprocess.argtypes = [C.c_void_p, C.c_int64, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p]
+    lib.lbm_hip_upcat.argtypes = [C.c_void_p] * 4 + [C.c_int32] * 3 + [C.c_void_p]
+    lib.lbm_hip_sample_queries.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p]
+    lib.lbm_hip_step_workspace_bytes.argtypes = [C.POINTER(StepDesc)]
+    lib.lbm_hip_track_step.argtypes = [C.POINTER(StepDesc), C.c_void_p]
+    lib.lbm_hip_conv2d_nhwc.argtypes = [C.c_void_p] * 6 + [C.c_int32] * 11 + [C.c_void_p]
+    lib.lbm_hip_maxpool3x3s2_nhwc.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p]
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise HipError(f"{what}: {load().lbm_hip_last_error().decode()}")
+
+
+def _require_gpu() -> None:
+    if not torch.cuda.is_available():
+        raise HipError("lbm_amd needs a ROCm GPU (gfx950); there is no CPU fallback")
+
+
+def _p(t: Optional[torch.Tensor], dtype=torch.float32) -> Optional[int]:
+    """Raw device pointer of a contiguous CUDA tensor of the expected dtype."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise HipError("expected a GPU tensor")
+    if dtype is not None and t.dtype != dtype:
+        if not (dtype == torch.uint8 and t.dtype == torch.bool):
+            raise HipError(f"expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise HipError("expected a contiguous tensor")
+    return t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+# ----------------------------------------------------------------------------------------------
+# op-level wrappers (used by the module mirrors and by the parity tests)
+# ----------------------------------------------------------------------------------------------
+
+def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = 0,
+           res: Optional[torch.Tensor] = None, res_div: int = 1, res_mod: int = 0, res_scale: float = 1.0,
+           ln: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, keep: Optional[torch.Tensor] = None,
+           fallback: Optional[torch.Tensor] = None, want_normed: bool = False, out: Optional[torch.Tensor] = None):
+    """y = act(x @ w.T + bias) + res_scale * res[(m // res_div) % res_mod]  (+ optional LayerNorm)."""
+    _require_gpu()
+    lib = load()
+    assert x.dim() == 2 and w.dim() == 2 and x.shape[1] == w.shape[1]
+    M, K = x.shape
+    N = w.shape[0]
+    y = out if out is not None else torch.empty(M, N, device=x.device, dtype=torch.float32)
+    yn = torch.empty(M, N, device=x.device, dtype=torch.float32) if want_normed else None
+    d = LinearDesc()
+    d.X, d.W, d.bias, d.Y, d.res = _p(x), _p(w), _p(bias), _p(y), _p(res)
+    d.M, d.N, d.K, d.ldx, d.ldw, d.ldy = M, N, K, K, K, N
+    d.ldres = res.shape[1] if res is not None else 0
+    d.res_div, d.res_mod, d.res_scale = res_div, res_mod, res_scale
+    d.act, d.batch = act, 1
+    if ln is not None:
+        d.ln_gamma, d.ln_beta = _p(ln[0]), _p(ln[1])
+        d.keep, d.fallback, d.Yn = _p(keep, torch.uint8), _p(fallback), _p(yn)
+    _check(lib.lbm_hip_linear(C.byref(d), _stream()), "lbm_hip_linear")
+    return (y, yn) if want_normed else y
+
+
+def linear_batched(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bias=None, act: int = 0,
+                   res: Optional[torch.Tensor] = None, strides: Sequence[int] = (0, 0, 0, 0, 0),
+                   M: int = 0, N: int = 0, K: int = 0, ldx: int = 0, ldw: int = 0, ldy: int = 0, ldres: int = 0,
+                   batch: int = 1, res_mod: int = 0) -> None:
+    """Raw strided/batched form (element strides sX, sW, sB, sY, sR)."""
+    _require_gpu()
+    d = LinearDesc()
+    d.X, d.W, d.bias, d.Y, d.res = x.data_ptr(), w.data_ptr(), _p(bias), out.data_ptr(), (res.data_ptr() if res is not None else None)
+    d.M, d.N, d.K, d.ldx, d.ldw, d.ldy, d.ldres = M, N, K, ldx, ldw, ldy, ldres
+    d.res_div, d.res_mod, d.res_scale, d.act, d.batch = 1, res_mod, 1.0, act, batch
+    d.sX, d.sW, d.sB, d.sY, d.sR = strides
+    _check(load().lbm_hip_linear(C.byref(d), _stream()), "lbm_hip_linear")
+
+
+def layernorm(x, gamma, beta, keep=None, fallback=None, want_normed=False):
+    _require_gpu()
+    y = torch.empty_like(x)
+    yn = torch.empty_like(x) if want_normed else None
+    rows = x.numel() // 256
+    _check(load().lbm_hip_layernorm(_p(x), _p(gamma), _p(beta), _p(y), rows, _p(keep, torch.uint8), _p(fallback), _p(yn),
+                                    _stream()), "lbm_hip_layernorm")
+    return (y, yn) if want_normed else y
+
+
+def l2norm(x: torch.Tensor) -> torch.Tensor:
+    _require_gpu()
+    y = torch.empty_like(x)
+    rows = x.numel() // 256
+    _check(load().lbm_hip_l2norm(_p(x), 256, _p(y), 256, rows, _stream()), "lbm_hip_l2norm")
+    return y
+
+
+def attn_readout(U, seq, S, ring_head=0, temb=None, mask_a=None, mask_b=None, want_valid=False):
+    """U (R,4,256); seq (R,S,256) -> (R,4,256) [and valid (R,) uint8]."""
+    _require_gpu()
+    R = U.shape[0]
+    out = torch.empty(R, 4, 256, device=U.device, dtype=torch.float32)
+    valid = torch.empty(R, device=U.device, dtype=torch.uint8) if want_valid else None
+    _check(load().lbm_hip_attn_readout(_p(U), _p(seq), S * 256, 256, S, ring_head, _p(temb), _p(mask_a, torch.uint8),
+                                       _p(mask_b, torch.uint8), _p(out), _p(valid, torch.uint8), R, _stream()),
+           "lbm_hip_attn_readout")
+    return (out, valid) if want_valid else out
+
+
+def pyramid(tokens: torch.Tensor, h: int, w: int) -> None:
+    _require_gpu()
+    _check(load().lbm_hip_pyramid(_p(tokens), tokens.shape[0], h, w, _stream()), "lbm_hip_pyramid")
+
+
+def corr_maps(tokens: torch.Tensor, corr_mix: Sequence[float], n_layers: int, h: int, w: int) -> torch.Tensor:
+    _require_gpu()
+    B, L, _ = tokens.shape
+    inv = torch.empty(B, L, device=tokens.device, dtype=torch.float32)
+    F = torch.empty(n_layers, B, h * w, 256, device=tokens.device, dtype=torch.float32)
+    mix = (C.c_float * (n_layers * 4))(*[float(v) for v in corr_mix])
+    _check(load().lbm_hip_corr_maps(_p(tokens), _p(inv), _p(F), mix, n_layers, B, h, w, _stream()), "lbm_hip_corr_maps")
+    return F
+
+
+def topk(corr: torch.Tensor, k: int, grid_w: int, stride_px: int = 4):
+    """corr (rows, P) -> idx (rows,k) int32, ref (rows,k,2) float, val (rows,k)."""
+    _require_gpu()
+    rows, P = corr.shape
+    idx = torch.empty(rows, k, device=corr.device, dtype=torch.int32)
+    ref = torch.empty(rows, k, 2, device=corr.device, dtype=torch.float32)
+    val = torch.empty(rows, k, device=corr.device, dtype=torch.float32)
+    _check(load().lbm_hip_topk(_p(corr), P, P, k, rows, grid_w, stride_px, _p(idx, torch.int32), _p(ref), _p(val), _stream()),
+           "lbm_hip_topk")
+    return idx, ref, val
+
+
+def _fill_levels(d: MsdaDesc, shapes: Sequence[Tuple[int, int]]) -> int:
+    st = 0
+    for l, (hl, wl) in enumerate(shapes):
+        d.lvl_h[l], d.lvl_w[l], d.lvl_start[l] = hl, wl, st
+        st += hl * wl
+    return st
+
+
+def msda_sample(value: torch.Tensor, shapes, offlog: torch.Tensor, ref: torch.Tensor, B: int, N: int, k: int, P: int,
+                net_w: float, net_h: float, vcol: int = 0) -> torch.Tensor:
+    """Implicit mode: value (B, L, ldv) [columns vcol..vcol+255 used], offlog (B*N, 48P), ref (B*N, k, 2) px."""
+    _require_gpu()
+    assert len(shapes) == 4
+    d = MsdaDesc()
+    L = _fill_levels(d, shapes)
+    ldv = value.shape[-1]
+    out = torch.empty(B * N * k, 256, device=value.device, dtype=torch.float32)
+    d.value = _p(value) + vcol * 4
+    d.v_batch_stride, d.ldv = L * ldv, ldv
+    d.B, d.N, d.k, d.P = B, N, k, P
+    d.offlog, d.ld_offlog, d.logit_col = _p(offlog), offlog.shape[-1], 32 * P
+    d.ref, d.net_w, d.net_h = _p(ref), net_w, net_h
+    d.out = _p(out)
+    _check(load().lbm_hip_msda_sample(C.byref(d), _stream()), "lbm_hip_msda_sample")
+    return out
+
+
+def msda_sample_loc(value: torch.Tensor, shapes, loc: torch.Tensor, attw: torch.Tensor, out: torch.Tensor) -> None:
+    """Explicit mode (generic operator): value (B,L,4,64), loc (B,Q,4,4,P,2), attw (B,Q,4,4,P), out (B,Q,256)."""
+    _require_gpu()
+    if len(shapes) != 4 or value.shape[2] != 4 or value.shape[3] != 64:
+        raise HipError("the gfx950 MSDA kernel is specialised for 4 levels, 4 heads x 64 channels")
+    B, L = value.shape[:2]
+    Q, P = loc.shape[1], loc.shape[4]
+    d = MsdaDesc()
+    _fill_levels(d, shapes)
+    d.value, d.v_batch_stride, d.ldv = _p(value), L * 256, 256
+    d.B, d.N, d.k, d.P = B, Q, 1, P
+    d.loc, d.attw, d.out = _p(loc), _p(attw), _p(out)
+    _check(load().lbm_hip_msda_sample(C.byref(d), _stream()), "lbm_hip_msda_sample")
+
+
+def msda_forward(mod, query, value, reference_points, shapes, identity) -> torch.Tensor:
+    """MultiScaleDeformableAttention.forward (msdeformattn.py:142-185) for batch-first inputs."""
+    _require_gpu()
+    B, Q, Cc = query.shape
+    L = value.shape[1]
+    P = mod.num_points
+    if Cc != 256 or mod.num_heads != 4 or mod.num_levels != 4:
+        raise HipError("the gfx950 MSDA kernel is specialised for embed_dims=256, 4 heads, 4 levels")
+    v = linear(value.reshape(B * L, Cc), mod.value_proj.weight.detach(), mod.value_proj.bias.detach()).view(B, L, 4, 64)
+    q2 = query.reshape(B * Q, Cc)
+    off = linear(q2, mod.sampling_offsets.weight.detach(), mod.sampling_offsets.bias.detach()).view(B, Q, 4, 4, P, 2)
+    aw = linear(q2, mod.attention_weights.weight.detach(), mod.attention_weights.bias.detach()).view(B, Q, 4, 4 * P)
+    aw = torch.softmax(aw, -1).view(B, Q, 4, 4, P).contiguous()
+    norm = torch.tensor([[wl, hl] for (hl, wl) in shapes], device=query.device, dtype=torch.float32)
+    loc = (reference_points[:, :, None, :, None, :] + off / norm[None, None, None, :, None, :]).contiguous()
+    samp = torch.empty(B, Q, 256, device=query.device, dtype=torch.float32)
+    msda_sample_loc(v, shapes, loc, aw, samp)
+    out = linear(samp.view(B * Q, 256), mod.output_proj.weight.detach(), mod.output_proj.bias.detach(),
+                 res=identity.reshape(B * Q, 256))
+    return out.view(B, Q, 256)
+
+
+def preprocess(frames: torch.Tensor, oh: int, ow: int, layout: int = 0) -> torch.Tensor:
+    """frames (B,3,H,W) fp32 in [0,255] -> normalised image.  layout 0: (B,3,oh,ow); 3 / 4: pixel-major
+    (B,oh,ow,layout) with channel 3 zero-filled (what the NHWC convolution stem reads)."""
+    _require_gpu()
+    B, Cc, H, W = frames.shape
+    assert Cc == 3 and layout in (0, 3, 4)
+    frames = frames.float().contiguous()
+    shape = (B, 3, oh, ow) if layout == 0 else (B, oh, ow, layout)
+    out = torch.empty(shape, device=frames.device, dtype=torch.float32)
+    _check(load().lbm_hip_preprocess(frames.data_ptr(), 3 * H * W, out.data_ptr(), B, H, W, oh, ow, layout, _stream()),
+           "lbm_hip_preprocess")
+    return out
+
+
+def upcat(p1, p2, p3, B, h, w) -> torch.Tensor:
+    _require_gpu()
+    out = torch.empty(B * h * w, 192, device=p1.device, dtype=torch.float32)
+    _check(load().lbm_hip_upcat(_p(p1), _p(p2), _p(p3), _p(out), B, h, w, _stream()), "lbm_hip_upcat")
+    return out
+
+
+def sample_queries(tokens: torch.Tensor, pts: torch.Tensor, h: int, w: int, net_h: int, net_w: int) -> torch.Tensor:
+    """tokens (B, rows>=h*w, 256) (a view with batch stride is fine), pts (B,N,2) network px -> (B,N,256)."""
+    _require_gpu()
+    B, N = pts.shape[:2]
+    if tokens.stride(2) != 1 or tokens.stride(1) != 256:
+        tokens = tokens.contiguous()
+    out = torch.empty(B, N, 256, device=tokens.device, dtype=torch.float32)
+    _check(load().lbm_hip_sample_queries(tokens.data_ptr(), tokens.stride(0), 256, _p(pts), _p(out), B, N, h, w, net_h, net_w,
+                                         _stream()), "lbm_hip_sample_queries")
+    return out
+
+
+def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, kh: int, kw: int, stride: int, pad: int,
+                relu: bool, res: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x (B,H,W,Cin) fp32; w_packed (Cout, kh*kw*Cin) tap-major; -> relu?(conv + bias (+ res)) as (B,Ho,Wo,Cout)."""
+    _require_gpu()
+    B, H, W, Cin = x.shape
+    Cout = w_packed.shape[0]
+    Ho = (H + 2 * pad - kh) // stride + 1
+    Wo = (W + 2 * pad - kw) // stride + 1
+    y = torch.empty(B, Ho, Wo, Cout, device=x.device, dtype=torch.float32)
+    _check(load().lbm_hip_conv2d_nhwc(_p(x), _p(w_packed), _p(bias), _p(res), _p(y), None, B, H, W, Cin, Cout, kh, kw, stride,
+                                      pad, 1 if relu else 0, w_packed.shape[1], _stream()), "lbm_hip_conv2d_nhwc")
+    return y
+
+
+def maxpool3x3s2_nhwc(x: torch.Tensor) -> torch.Tensor:
+    _require_gpu()
+    B, H, W, Cc = x.shape
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    y = torch.empty(B, Ho, Wo, Cc, device=x.device, dtype=torch.float32)
+    _check(load().lbm_hip_maxpool3x3s2_nhwc(_p(x), _p(y), B, H, W, Cc, _stream()), "lbm_hip_maxpool3x3s2_nhwc")
+    return y

@@ -1,0 +1,178 @@
+"""Stateful online tracker (reference: lbm/models/lbm_online.py:10-200), generalised to B streams.
+
+``init`` / ``update`` / ``online_forward`` keep the reference signatures and return values.  Differences on purpose
+(MI355X-first, semantics preserved):
+
+* the two per-point memories are **ring buffers** in HBM: a frame overwrites the oldest slot in place instead of
+  ``torch.cat``-shifting 2 x (N, M, C) floats and cloning the whole state five times per frame
+  (lbm_online.py:133-146).  ``collision_dist`` / ``stream_dist`` / ``vis_mask`` / ``mem_mask`` are exposed as
+  properties that materialise the reference's logical (oldest-first) order on demand;
+* no host synchronisation inside a frame (the reference's ``.item()`` / ``nonzero`` / ``assert`` syncs are gone);
+* ``init_streams`` / ``online_forward_batch`` run B independent streams in one step (BASELINE configs 3-4).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import hip
+from .lbm import LBM
+
+
+class LBM_online(LBM):
+    def __init__(self, args, with_obj_tracker: bool = False):
+        super().__init__(args=args)
+        self.num_query = None
+        self.t = 0
+        self.N = 0
+        self.B = 1
+        self.query = None           # (B, N, C)
+        self.query_points = None
+        self._stream = None         # (B, N, M, C) physical ring order
+        self._coll = None
+        self._vis = None            # (B, N, M) uint8
+        self._mem = None
+        self._head = 0
+        self.img_size = None
+        self.device = "cuda" if torch.cuda.is_available() else "cpu"
+        if with_obj_tracker:
+            raise NotImplementedError("the object-tracking association layer (object_tracker.py) is outside the hot path "
+                                      "(SURVEY §8 f.1); update() below provides the add/remove-points primitive it drives")
+
+    # ---- logical (oldest-first) views of the ring state, reference layout (1|B, N, M, ...) ----
+    def _logical(self, x: Optional[torch.Tensor]):
+        if x is None:
+            return None
+        M = x.shape[2]
+        order = (torch.arange(M, device=x.device) + self._head) % M
+        return x.index_select(2, order)
+
+    @property
+    def stream_dist(self):
+        return self._logical(self._stream)
+
+    @property
+    def collision_dist(self):
+        return self._logical(self._coll)
+
+    @property
+    def vis_mask(self):
+        v = self._logical(self._vis)
+        return None if v is None else v.bool()
+
+    @property
+    def mem_mask(self):
+        v = self._logical(self._mem)
+        return None if v is None else v.bool()
+
+    def _alloc_state(self, B: int, N: int) -> None:
+        dev, M, Cc = self.device, self.memory_size, self.embed_dim
+        self._stream = torch.zeros(B, N, M, Cc, device=dev)
+        self._coll = torch.zeros(B, N, M, Cc, device=dev)
+        self._vis = torch.ones(B, N, M, device=dev, dtype=torch.uint8)
+        self._mem = torch.ones(B, N, M, device=dev, dtype=torch.uint8)
+        self._head = 0
+
+    def _to_net_px(self, pts: torch.Tensor) -> torch.Tensor:
+        H, W = self.img_size
+        out = pts.clone().float()
+        out[..., 1] = (out[..., 1] / H) * self.size[0]
+        out[..., 0] = (out[..., 0] / W) * self.size[1]
+        return out
+
+    # ---- reference API (B = 1) ----------------------------------------------------------------
+    @torch.no_grad()
+    def init(self, query_points: torch.Tensor, first_frame: torch.Tensor) -> None:
+        """lbm_online.py:27-46 — query_points (N,2) xy in frame pixels; first_frame (1,3,H,W) in [0,255]."""
+        self.query_points = query_points
+        self.N = query_points.shape[0]
+        self.B = 1
+        self.img_size = first_frame.shape[-2:]
+        self.device = first_frame.device
+        self.t = 0
+        self.query = None
+        tok = self.backbone.encode_tokens(first_frame)
+        update_mask = torch.ones(self.N, device=self.device, dtype=torch.bool)
+        remove_mask = torch.zeros(self.N, device=self.device, dtype=torch.bool)
+        self.update(self.query_points, tok, update_mask, remove_mask)
+
+    @torch.no_grad()
+    def update(self, query_points, frame_feat, update_mask, remove_mask) -> None:
+        """lbm_online.py:48-112 — add / remove tracked points.  ``frame_feat`` is either the (1,L,C) token buffer
+        of the current frame or the (1,C,h,w) map ``online_forward`` returned."""
+        N = query_points.shape[0]
+        if N > 0:
+            if frame_feat.dim() == 4:       # (1,C,h,w) view -> token-major
+                frame_feat = frame_feat.permute(0, 2, 3, 1).reshape(1, self.h * self.w, self.embed_dim)
+            remove_mask = remove_mask[: self.N].bool()
+            update_mask = update_mask.bool()
+            keep = ~remove_mask
+            n_prev = int(keep.sum())
+            pts = self._to_net_px(query_points[update_mask].to(self.device)).unsqueeze(0).contiguous()
+            new_q = self.backbone.sample_points(frame_feat, pts)            # (1, n_update, C)
+            old = (self.query, self._stream, self._coll, self._vis, self._mem, self._head)
+            self._alloc_state(1, N)
+            query = torch.zeros(1, N, self.embed_dim, device=self.device)
+            if old[0] is not None and n_prev > 0:
+                M = self.memory_size
+                order = (torch.arange(M, device=self.device) + old[5]) % M   # back to logical order, head = 0
+                query[:, :n_prev] = old[0][:, keep]
+                self._stream[:, :n_prev] = old[1][:, keep].index_select(2, order)
+                self._coll[:, :n_prev] = old[2][:, keep].index_select(2, order)
+                self._vis[:, :n_prev] = old[3][:, keep].index_select(2, order)
+                self._mem[:, :n_prev] = old[4][:, keep].index_select(2, order)
+                query[:, update_mask] = new_q
+            else:
+                query = new_q
+            self.query = query.contiguous()
+            self.query_points = query_points
+        self.N = N
+        self.B = 1
+
+    @torch.no_grad()
+    def online_forward(self, frame: torch.Tensor):
+        """lbm_online.py:114-158 — frame (1,3,H,W) in [0,255] -> (coord (N,2) frame px, vis (N,) bool, rho (N,), f_t (1,C,h,w))."""
+        if self.query is None:
+            raise RuntimeError("online_forward called before init()/update() registered any query point")
+        coords, vis, rho, tok = self.online_forward_batch(frame)
+        f_t = tok[:, : self.h * self.w].view(-1, self.h, self.w, self.embed_dim).permute(0, 3, 1, 2)
+        return coords[0], vis[0], rho[0], f_t
+
+    # ---- multi-stream API ---------------------------------------------------------------------
+    @torch.no_grad()
+    def init_streams(self, query_points: torch.Tensor, first_frames: torch.Tensor) -> None:
+        """query_points (B,N,2) xy frame pixels; first_frames (B,3,H,W).  B independent streams, one state."""
+        B, N = query_points.shape[:2]
+        self.B, self.N = B, N
+        self.img_size = first_frames.shape[-2:]
+        self.device = first_frames.device
+        self.t = 0
+        self.query_points = query_points
+        tok = self.backbone.encode_tokens(first_frames)
+        self.query = self.backbone.sample_points(tok, self._to_net_px(query_points.to(self.device)).contiguous())
+        self._alloc_state(B, N)
+
+    @torch.no_grad()
+    def online_forward_batch(self, frames: torch.Tensor, tokens: Optional[torch.Tensor] = None):
+        """frames (B,3,H,W) -> coords (B,N,2) frame px, vis (B,N) bool, rho (B,N) in (0,1), tokens (B,L,C)."""
+        H, W = frames.shape[-2], frames.shape[-1]
+        tok = self.backbone.encode_tokens(frames, tokens)
+        out = self.transformer.get_engine().step(tok, self.query, self._stream, self._coll, self._vis, self._mem,
+                                                 ring_head=self._head, queried=None, update_state=True, img_hw=(H, W),
+                                                 vis_threshold=self.visibility_treshold)
+        self._head = (self._head + 1) % self.memory_size
+        self.t += 1
+        self.last_logits = (out["vis"], out["rho"])
+        return out["coords"], torch.sigmoid(out["vis"]) > self.visibility_treshold, torch.sigmoid(out["rho"]), tok
+
+    def online_forward_obj(self, frame, bboxes, scores, labels):
+        raise NotImplementedError("object tracking (lbm_online.py:160-200, object_tracker.py) is outside the hot path")
+
+
+class LBM_export(LBM):
+    """Placeholder for import compatibility: the ONNX/TensorRT export variant (lbm_online.py:203-353) is out of
+    scope (and broken in the reference at this commit)."""
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("ONNX/TensorRT export is out of scope")

@@ -270,7 +270,9 @@ int lbm_hip_version(void) { return LBM_HIP_ABI_VERSION; }
 const char* lbm_hip_last_error(void) { return g_err; }
 
 int lbm_hip_linear(const lbm_hip_linear_desc* d, lbm_stream_t stream) {
-  LBM_REQUIRE(d && d->X && d->W && d->Y, "linear: null argument");
+  LBM_REQUIRE(d != nullptr, "linear: null descriptor");
+  if (d->M == 0) return 0;
+  LBM_REQUIRE(d->X && d->W && d->Y, "linear: null argument");
   GemmArgs a;
   a.X = d->X; a.W = d->W; a.bias = d->bias; a.Y = d->Y; a.res = d->res;
   a.M = d->M; a.N = d->N; a.K = d->K; a.ldx = d->ldx; a.ldw = d->ldw; a.ldy = d->ldy; a.ldres = d->ldres;

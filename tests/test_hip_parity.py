@@ -1,0 +1,381 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle and against the golden outputs
+of the reference (tests/golden/*.npz).  Tolerances (BASELINE.json north_star): coordinates 0.05 px, logits 1e-4 (fp32).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fixtures as fx
+from oracle import lbm_ref_cpu as ref
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_TOL = 1e-4      # fp32 bar of the north star
+COORD_TOL = 0.05      # px
+FEAT_TOL = dict(rtol=2e-4, atol=2e-4)
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from lbm_amd import hip as h
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    h.load()
+    return h
+
+
+def _cmp(a, b, **tol):
+    a = a.detach().float().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().float().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    np.testing.assert_allclose(a, b, **tol)
+
+
+def _transformer(g, seed=42):
+    from lbm_amd.transformer import LBMTransformer
+    tr = LBMTransformer(size=list(g.size), stride=g.stride, n_layer=g.num_layers, hidden_dim=g.embed_dim, n_head=g.num_heads,
+                        n_level=g.num_levels, n_neighbor=g.num_neighbors, n_mem=g.memory_size, n_topk=g.top_k_regions)
+    sd = fx.transformer_state_dict(g, seed)
+    tr.load_state_dict(sd, strict=True)
+    return tr.cuda().eval(), sd
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# op level
+# ---------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("M,N,K", [(1, 256, 256), (37, 1024, 256), (300, 256, 1024), (1020, 1536, 256), (4096, 288, 256),
+                                   (513, 130, 64), (0, 256, 256)])
+def test_linear_against_fp64(hip, M, N, K):
+    r = np.random.default_rng(M * 7 + N)
+    x = torch.from_numpy(r.normal(size=(M, K)).astype(np.float32)).cuda()
+    w = torch.from_numpy(r.normal(size=(N, K)).astype(np.float32)).cuda()
+    b = torch.from_numpy(r.normal(size=(N,)).astype(np.float32)).cuda()
+    y = hip.linear(x, w, b)
+    want = x.double() @ w.double().t() + b.double()
+    _cmp(y, want, rtol=1e-5, atol=1e-4)
+    y = hip.linear(x, w, b, act=1)
+    _cmp(y, torch.nn.functional.gelu(want), rtol=1e-5, atol=1e-4)
+
+
+def test_linear_residual_layernorm_keep(hip):
+    r = np.random.default_rng(3)
+    M, K = 77, 1024
+    x = torch.from_numpy(r.normal(size=(M, K)).astype(np.float32)).cuda()
+    w = torch.from_numpy(r.normal(size=(256, K)).astype(np.float32) * 0.05).cuda()
+    b = torch.from_numpy(r.normal(size=(256,)).astype(np.float32)).cuda()
+    res = torch.from_numpy(r.normal(size=(11, 256)).astype(np.float32)).cuda()
+    gam = torch.from_numpy(r.normal(1, 0.1, size=(256,)).astype(np.float32)).cuda()
+    bet = torch.from_numpy(r.normal(size=(256,)).astype(np.float32)).cuda()
+    keep = torch.from_numpy((r.uniform(size=M) < 0.6).astype(np.uint8)).cuda()
+    fb = torch.from_numpy(r.normal(size=(M, 256)).astype(np.float32)).cuda()
+    y, yn = hip.linear(x, w, b, res=res, res_div=7, res_scale=2.0, ln=(gam, bet), keep=keep, fallback=fb, want_normed=True)
+    rows = torch.arange(M, device="cuda") // 7
+    pre = x @ w.t() + b + 2.0 * res[rows]
+    want = torch.nn.functional.layer_norm(pre, (256,), gam, bet, 1e-5)
+    want = torch.where(keep.bool().unsqueeze(1), want, fb)
+    _cmp(y, want, rtol=1e-4, atol=1e-4)
+    _cmp(yn, torch.nn.functional.normalize(want, dim=-1), rtol=1e-4, atol=1e-5)
+
+
+def test_pyramid_and_corr_maps_against_reference_correlation(hip, golden):
+    spec, g = fx.GEOMS["small256"], fx.geometry("small256")
+    gold = golden("corr_small256")
+    tr, sd = _transformer(g)
+    inp = fx.step_inputs(g, spec["B"], spec["N"], seed=21)
+    tok = tr.tokens_from_feat(inp["feat"].cuda())
+    P0 = g.h * g.w
+    _cmp(tok[:, P0:P0 + P0 // 4], gold["pyr1"], rtol=1e-6, atol=1e-6)
+    _cmp(tok[:, -P0 // 64:], gold["pyr3"], rtol=1e-6, atol=1e-6)
+    mix = sd["layers.1.corr_conv.weight"].flatten().tolist()
+    F = hip.corr_maps(tok, mix, 1, g.h, g.w)[0]                         # (B, P0, C)
+    qn = hip.l2norm(inp["query"].cuda().contiguous())
+    corr = torch.einsum("bnc,bpc->bnp", qn, F) + float(sd["layers.1.corr_conv.bias"])
+    _cmp(corr, gold["corr"], rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("k", [1, 4, 9, 16])
+def test_topk_is_exact_with_lowest_index_ties(hip, k):
+    r = np.random.default_rng(k)
+    rows, P = 37, 3072
+    c = r.normal(size=(rows, P)).astype(np.float32)
+    c[:, 100] = c[:, 2000] = 50.0          # exact ties: the lower index must win
+    c[3, :] = 1.0                          # a fully tied row
+    idx, refp, val = hip.topk(torch.from_numpy(c).cuda(), k, grid_w=64)
+    order = np.lexsort((np.arange(P)[None, :].repeat(rows, 0), -c), axis=1)[:, :k]
+    assert (idx.cpu().numpy() == order).all()
+    _cmp(val, np.take_along_axis(c, order, 1), rtol=0, atol=0)
+    _cmp(refp[..., 0], (order % 64) * 4 + 2.0, rtol=0, atol=0)
+    _cmp(refp[..., 1], (order // 64) * 4 + 2.0, rtol=0, atol=0)
+
+
+def test_msda_operator_against_reference_golden(hip, golden):
+    """The operator seam: MultiScaleDeformableAttention.forward (msdeformattn.py:85-185)."""
+    from lbm_amd.msdeformattn import MultiScaleDeformableAttention
+    from lbm_amd.synth import synthetic_state_dict
+    g = fx.geometry("small256")
+    gold = golden("msda_small256")
+    shapes = torch.tensor(g.level_shapes, dtype=torch.long)
+    starts = torch.tensor(g.level_starts, dtype=torch.long)
+    for P in (9, 4):
+        m = MultiScaleDeformableAttention(g.embed_dim, g.num_heads, g.num_levels, P, batch_first=True)
+        m.load_state_dict(synthetic_state_dict(m, seed=100 + P), strict=True)
+        m = m.cuda().eval()
+        inp = {k: v.cuda() for k, v in fx.msda_inputs(g, 2, 24, seed=13 + P).items()}
+        with torch.no_grad():
+            y = m(inp["query"], inp["value"], inp["value"], reference_points=inp["reference_points"], spatial_shapes=shapes,
+                  level_start_index=starts)
+        _cmp(y, gold[f"out_p{P}"], rtol=1e-4, atol=1e-4)
+
+
+def test_msda_core_function_against_oracle(hip):
+    from lbm_amd.msdeformattn import multi_scale_deformable_attn_pytorch
+    g = fx.geometry("full256")
+    r = np.random.default_rng(5)
+    B, Q, P = 2, 50, 9
+    value = torch.from_numpy(r.normal(size=(B, g.num_tokens, 4, 64)).astype(np.float32))
+    loc = torch.from_numpy(r.uniform(-0.1, 1.1, size=(B, Q, 4, 4, P, 2)).astype(np.float32))
+    attw = torch.softmax(torch.from_numpy(r.normal(size=(B, Q, 4, 4 * P)).astype(np.float32)), -1).view(B, Q, 4, 4, P)
+    want = ref.msda_core(value, g.level_shapes, loc, attw)
+    got = multi_scale_deformable_attn_pytorch(value.cuda(), torch.tensor(g.level_shapes), loc.cuda(), attw.cuda())
+    _cmp(got, want, rtol=1e-5, atol=1e-5)
+
+
+def test_attention_readout_ring_and_masks(hip):
+    """nn.MultiheadAttention for a 1-token query over a ring-ordered memory, via the folded weights."""
+    from lbm_amd.engine import fold_attention
+    r = np.random.default_rng(11)
+    R, M, C = 45, 12, 256
+    mha = torch.nn.MultiheadAttention(C, 4, batch_first=True).eval()
+    with torch.no_grad():
+        mha.in_proj_bias.normal_(0, 0.1)
+        mha.out_proj.bias.normal_(0, 0.1)
+    temb = torch.from_numpy(r.normal(0, 0.5, size=(1, M + 1, C)).astype(np.float32))
+    x = torch.from_numpy(r.normal(size=(R, C)).astype(np.float32))
+    mem = torch.from_numpy(r.normal(size=(R, M, C)).astype(np.float32))
+    mask = torch.from_numpy(r.uniform(size=(R, M)) < 0.4)
+    mask[0] = True
+    mask[1] = False
+    valid = ~mask.all(-1)
+    with torch.no_grad():
+        q = (x + temb[0, -1]).unsqueeze(1)
+        want, _ = mha(q[valid], mem[valid] + temb[:, :-1], mem[valid], key_padding_mask=mask[valid], need_weights=False)
+        want = (q[valid] + want).squeeze(1)
+    G, gb, Hm, hb = [t.float().cuda() for t in fold_attention(mha, temb[0, -1])]
+    head = 5
+    phys = torch.roll(mem, shifts=head, dims=1).contiguous().cuda()          # logical j lives in slot (head + j) % M
+    pmask = torch.roll(mask, shifts=head, dims=1).contiguous().cuda()
+    U = hip.linear(x.cuda(), G, gb)
+    mbar, v = hip.attn_readout(U.view(R, 4, C), phys, M, ring_head=head, temb=temb[0, :-1].contiguous().cuda(),
+                               mask_a=pmask.to(torch.uint8), mask_b=None, want_valid=True)
+    got = hip.linear(mbar.view(R, 4 * C), Hm, hb, res=x.cuda())
+    assert (v.bool().cpu() == valid).all()
+    _cmp(got[valid.cuda()], want, rtol=1e-4, atol=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# step level
+# ---------------------------------------------------------------------------------------------------------------
+
+def _check_step(out, memory, offset, vis, rho, gold, B, N):
+    for i, o in enumerate(out):
+        # top-k: identical selection whenever the reference's own k / k+1 margin is not a numerical tie
+        ti, tv = gold[f"topi{i}"], gold[f"topv{i}"]
+        k = o["reference_points"].shape[2]
+        stable = (tv[..., k - 1] - tv[..., k]) > 1e-5
+        got = o["topk_indices"].cpu().numpy()
+        same = np.sort(got, -1) == np.sort(ti[..., :k], -1)
+        assert same.all(-1)[stable].all(), f"layer {i}: top-{k} cells differ from the reference"
+        if stable.all():
+            _cmp(o["reference_rho"].sort(-1)[0], np.sort(gold[f"rho{i}"], -1), rtol=1e-4, atol=LOGIT_TOL)
+    _cmp(out[-1]["reference_points"], gold[f"ref{len(out) - 1}"], rtol=0, atol=0)
+    _cmp(offset, gold["offset"], rtol=0, atol=1e-4)
+    _cmp(vis, gold["vis"], rtol=0, atol=LOGIT_TOL)
+    _cmp(rho, gold["rho"], rtol=0, atol=LOGIT_TOL)
+    _cmp(memory["stream"], gold["mem_stream"], **FEAT_TOL)
+    _cmp(memory["collision"], gold["mem_collision"], **FEAT_TOL)
+
+
+@pytest.mark.parametrize("name", ["small256", "full256"])
+def test_transformer_forward_against_reference_golden(hip, golden, name):
+    """LBMTransformer.forward (transformer.py:74-151) on the reference's own outputs."""
+    spec, g = fx.GEOMS[name], fx.geometry(name)
+    gold = golden("step_" + name)
+    tr, _ = _transformer(g)
+    tr.return_corr = True
+    inp = {k: v.cuda() for k, v in fx.step_inputs(g, spec["B"], spec["N"]).items()}
+    with torch.no_grad():
+        out, memory, offset, vis, rho = tr(inp["query"], inp["feat"], inp["stream"], inp["collision"], inp["vis_mask"],
+                                           inp["mem_mask"], inp["queried"])
+    _check_step(out, memory, offset, vis, rho, gold, spec["B"], spec["N"])
+    for i, o in enumerate(out):
+        if f"corr{i}" in gold:
+            _cmp(o["corr"], gold[f"corr{i}"], rtol=1e-4, atol=5e-5)
+        else:
+            _cmp(o["corr"][..., ::13], gold[f"corr_s{i}"], rtol=1e-4, atol=5e-5)
+
+
+def test_transformer_forward_against_oracle_full_geometry_many_points(hip):
+    """N = 300 points (not a multiple of any tile), B = 2, published geometry, oracle on the host."""
+    g = fx.geometry("full256")
+    tr, sd = _transformer(g)
+    inp = fx.step_inputs(g, 2, 300, seed=77)
+    with torch.no_grad():
+        want = ref.transformer_forward(sd, g, inp["query"], inp["feat"], inp["stream"], inp["collision"], inp["vis_mask"],
+                                       inp["mem_mask"], inp["queried"], prefix="")
+        cu = {k: v.cuda() for k, v in inp.items()}
+        got = tr(cu["query"], cu["feat"], cu["stream"], cu["collision"], cu["vis_mask"], cu["mem_mask"], cu["queried"])
+    w_out, w_mem, w_off, w_vis, w_rho = want
+    g_out, g_mem, g_off, g_vis, g_rho = got
+    ref_same = (g_out[-1]["reference_points"].cpu() == w_out[-1]["reference_points"]).all(-1).all(-1)
+    assert ref_same.float().mean().item() == 1.0, "arg-max cell differs from the oracle"
+    _cmp(g_off, w_off, rtol=0, atol=1e-4)
+    _cmp(g_vis, w_vis, rtol=0, atol=LOGIT_TOL)
+    _cmp(g_rho, w_rho, rtol=0, atol=LOGIT_TOL)
+    _cmp(g_mem["stream"], w_mem["stream"], **FEAT_TOL)
+    _cmp(g_mem["collision"], w_mem["collision"], **FEAT_TOL)
+
+
+def test_empty_point_set_is_a_no_op(hip):
+    g = fx.geometry("small256")
+    tr, _ = _transformer(g)
+    inp = {k: v.cuda() for k, v in fx.step_inputs(g, 1, 8).items()}
+    z = lambda t: t[:, :0].contiguous()
+    with torch.no_grad():
+        out, memory, offset, vis, rho = tr(z(inp["query"]), inp["feat"], z(inp["stream"]), z(inp["collision"]),
+                                           z(inp["vis_mask"]), z(inp["mem_mask"]), z(inp["queried"]))
+    assert offset.shape == (1, 0, 2) and vis.shape == (1, 0)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# sequence level: ring-buffer state against the reference's cat-shifted state
+# ---------------------------------------------------------------------------------------------------------------
+
+def test_sequence_ring_buffer_state_against_reference_golden(hip, golden):
+    name = "small256"
+    spec, g = fx.GEOMS[name], fx.geometry(name)
+    gold = golden("seq_" + name)
+    T = gold["coords"].shape[1]
+    B, N, M, C = spec["B"], spec["N"], g.memory_size, g.embed_dim
+    tr, _ = _transformer(g)
+    eng = tr.get_engine()
+    feats = fx.sequence_feats(g, B, T).cuda()
+    q_init = fx.step_inputs(g, B, N, seed=33)["query"].cuda()
+    times = torch.from_numpy(gold["times"]).cuda()
+    stream = torch.zeros(B, N, M, C, device="cuda")
+    coll = torch.zeros(B, N, M, C, device="cuda")
+    vmask = torch.ones(B, N, M, device="cuda", dtype=torch.uint8)
+    mmask = torch.ones(B, N, M, device="cuda", dtype=torch.uint8)
+    coords, vis, rho = [], [], []
+    for t in range(T):
+        tok = tr.tokens_from_feat(feats[t])
+        out = eng.step(tok, q_init, stream, coll, vmask, mmask, ring_head=t % M, queried=(times <= t).to(torch.uint8),
+                       update_state=True)
+        coords.append(out["coords"]), vis.append(out["vis"]), rho.append(out["rho"])
+    _cmp(torch.stack(coords, 1), gold["coords"], rtol=0, atol=COORD_TOL)
+    _cmp(torch.stack(vis, 1), gold["vis"], rtol=0, atol=LOGIT_TOL * 3)     # 7 chained frames
+    _cmp(torch.stack(rho, 1), gold["rho"], rtol=0, atol=LOGIT_TOL * 3)
+    order = (torch.arange(M, device="cuda") + (T % M)) % M                   # physical -> logical (oldest first)
+    _cmp(stream.index_select(2, order), gold["final_stream"], rtol=5e-4, atol=5e-4)
+    _cmp(coll.index_select(2, order), gold["final_collision"], rtol=5e-4, atol=5e-4)
+    assert (vmask.index_select(2, order).bool().cpu().numpy() == gold["final_vis_mask"]).all()
+    assert (mmask.index_select(2, order).bool().cpu().numpy() == gold["final_mem_mask"]).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# encoder and the online wrapper
+# ---------------------------------------------------------------------------------------------------------------
+
+def _online(cfg_kw, seed=42):
+    from lbm_amd.config import LBMConfig
+    from lbm_amd.lbm_online import LBM_online
+    from lbm_amd.synth import synthetic_state_dict
+    cfg = LBMConfig(**cfg_kw)
+    model = LBM_online(cfg.to_namespace())
+    sd = synthetic_state_dict(model, seed=seed)
+    model.load_state_dict(sd, strict=True)
+    return model.cuda().eval(), sd
+
+
+@pytest.mark.parametrize("size,frame", [((96, 128), (120, 160)), ((384, 512), (480, 854))])
+def test_encoder_against_oracle(hip, size, frame):
+    from lbm_amd.synth import synthetic_video
+    model, sd = _online(dict(input_size=size, memory_size=4))
+    g = ref.Geometry(size=size, memory_size=4)
+    video = synthetic_video(2, frame[0], frame[1], seed=9)
+    frames = video[0]                                                    # (2,3,H,W): a batch of two frames
+    with torch.no_grad():
+        want = ref.encode_frames(sd, g, frames)                          # (2,C,h,w)
+        tok = model.backbone.encode_tokens(frames.cuda())
+        got = tok[:, : g.h * g.w].view(2, g.h, g.w, -1).permute(0, 3, 1, 2)
+        x = ref.preprocess(frames, size)
+        _cmp(hip.preprocess(frames.cuda(), size[0], size[1]), x, rtol=1e-5, atol=1e-5)
+    _cmp(got, want, rtol=1e-3, atol=1e-3)
+    want_pyr = ref.pyramid(want)
+    _cmp(tok[:, g.h * g.w: g.h * g.w + (g.h * g.w) // 4], want_pyr[1], rtol=1e-3, atol=1e-3)
+
+
+def test_online_tracker_against_oracle_sequence(hip):
+    """LBM_online.init / online_forward (lbm_online.py:27-158) end to end, encoder included, published geometry."""
+    from lbm_amd.synth import synthetic_video, grid_queries
+    model, sd = _online(dict(input_size=(384, 512), memory_size=12))
+    g = ref.Geometry(size=(384, 512), memory_size=12)
+    T, H, W = 5, 480, 854
+    video = synthetic_video(T, H, W, seed=4)
+    pts = grid_queries(H, W, 5)
+    oracle = ref.RefOnline(sd, g)
+    with torch.no_grad():
+        model.init(pts.cuda(), video[:, 0].cuda())
+        oracle.init(pts, video[:, 0])
+        _cmp(model.query, oracle.state.query, rtol=1e-3, atol=1e-3)
+        for t in range(1, T):
+            c, v, r, f_t = model.online_forward(video[:, t].cuda())
+            oc, ov, orr, ofeat, ovl, orl = oracle.online_forward(video[:, t])
+            assert f_t.shape == ofeat.shape
+            _cmp(c, oc, rtol=0, atol=COORD_TOL)
+            _cmp(model.last_logits[0][0], ovl, rtol=0, atol=1e-3)       # encoder + tracker chained
+            _cmp(r, orr, rtol=0, atol=1e-3)
+            stable = (torch.sigmoid(ovl) - 0.8).abs() > 1e-3
+            assert (v.cpu()[stable] == ov[stable]).all()
+    assert model.t == T - 1
+    _cmp(model.stream_dist, oracle.state.stream, rtol=2e-3, atol=2e-3)
+    assert (model.vis_mask.cpu() == oracle.state.vis_mask).all()
+
+
+def test_inference_late_queries_against_oracle(hip):
+    """LBM.inference (lbm.py:211-280): per-point query times, points before their query frame."""
+    from lbm_amd.synth import synthetic_video
+    model, sd = _online(dict(input_size=(96, 128), memory_size=4))
+    g = ref.Geometry(size=(96, 128), memory_size=4)
+    T, H, W = 6, 120, 160
+    video = synthetic_video(T, H, W, seed=6)
+    r = np.random.default_rng(2)
+    N = 10
+    q = np.stack([r.integers(0, 4, N), r.uniform(10, W - 10, N), r.uniform(10, H - 10, N)], -1).astype(np.float32)
+    q[0, 0] = 0
+    queries = torch.from_numpy(q).unsqueeze(0)
+    with torch.no_grad():
+        want_pts, want_vis = ref.inference(sd, g, video, queries)
+        got = model.inference(video.cuda(), queries.clone().cuda())
+    _cmp(got["points"], want_pts, rtol=0, atol=COORD_TOL)
+    stable = (torch.sigmoid(want_vis) - 0.8).abs() > 1e-3
+    assert (got["visibility"].cpu()[stable] == (torch.sigmoid(want_vis) > 0.8)[stable]).all()
+
+
+def test_set_memory_size_against_oracle(hip):
+    model, sd = _online(dict(input_size=(96, 128), memory_size=12))
+    g = ref.Geometry(size=(96, 128), memory_size=12)
+    sd = {k: v.clone() for k, v in sd.items()}
+    ref.resize_time_embeddings(sd, g, 20)
+    model.set_memory_size(20)
+    for i in range(3):
+        _cmp(model.transformer.layers[i].stream_time_emb, sd[f"transformer.layers.{i}.stream_time_emb"], rtol=1e-5, atol=1e-6)
+    B, N = 1, 12
+    inp = fx.step_inputs(g, B, N, seed=5)
+    tsd = {k[len("transformer."):]: v for k, v in sd.items() if k.startswith("transformer.")}
+    with torch.no_grad():
+        want = ref.transformer_forward(tsd, g, inp["query"], inp["feat"], inp["stream"], inp["collision"], inp["vis_mask"],
+                                       inp["mem_mask"], inp["queried"], prefix="")
+        cu = {k: v.cuda() for k, v in inp.items()}
+        got = model.transformer(cu["query"], cu["feat"], cu["stream"], cu["collision"], cu["vis_mask"], cu["mem_mask"],
+                                cu["queried"])
+    _cmp(got[3], want[3], rtol=0, atol=LOGIT_TOL)
+    _cmp(got[2], want[2], rtol=0, atol=1e-4)

@@ -220,6 +220,20 @@ typedef struct {
 uint64_t lbm_hip_step_workspace_bytes(const lbm_hip_step_desc* d);
 int lbm_hip_track_step(const lbm_hip_step_desc* d, lbm_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Measurement aid (no counterpart in the reference, which only has wall-clock timing, benchmark_torch.py:71-76):
+ * between _begin and _end every kernel launch of this library is bracketed by HIP events on its launch stream;
+ * _end synchronises on them and returns one aggregated entry per kernel (launch count, summed event time,
+ * summed algorithmic flops / bytes as defined in DESIGN.md).  Returns the number of distinct kernels (entries
+ * beyond `cap` are dropped) or a negative value.  Not thread-safe; adds ~2 events per launch while enabled.  */
+typedef struct {
+  char name[96];
+  int64_t launches;
+  double total_ms, flops, bytes;
+} lbm_hip_profile_entry;
+int lbm_hip_profile_begin(void);
+int lbm_hip_profile_end(lbm_hip_profile_entry* out, int32_t cap);
+
 /* debugging aid for parity tests: byte offset of a named intermediate inside the workspace, or -1 */
 int64_t lbm_hip_step_workspace_offset(const lbm_hip_step_desc* d, const char* name);
 

@@ -2,6 +2,10 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <map>
+#include <string>
+#include <vector>
+
 #include "../../include/lbm_hip.h"
 #include "attn.hpp"
 #include "common.hpp"
@@ -30,6 +34,28 @@ int check_launch(const char* what) {
     return -1;
   }
   return 0;
+}
+
+// ---- per-launch timing ---------------------------------------------------------------------------
+struct ProfRec {
+  const char* name;
+  hipEvent_t e0, e1;
+  double flops, bytes;
+};
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+static const size_t kProfMax = 1 << 16;
+
+ProfScope::ProfScope(const char* name, hipStream_t s, double flops, double bytes) : slot(-1), stream(s) {
+  if (!g_prof_on || g_prof.size() >= kProfMax) return;
+  ProfRec r{name, nullptr, nullptr, flops, bytes};
+  if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+  (void)hipEventRecord(r.e0, s);
+  g_prof.push_back(r);
+  slot = (int)g_prof.size() - 1;
+}
+ProfScope::~ProfScope() {
+  if (slot >= 0) (void)hipEventRecord(g_prof[slot].e1, stream);
 }
 
 // ---- workspace layout of the step --------------------------------------------------------------
@@ -357,6 +383,49 @@ int lbm_hip_conv2d_nhwc(const float* X, const float* W, const float* bias, const
 
 int lbm_hip_maxpool3x3s2_nhwc(const float* x, float* y, int32_t B, int32_t H, int32_t W, int32_t C, lbm_stream_t stream) {
   return maxpool3x3s2_nhwc(x, y, B, H, W, C, (hipStream_t)stream);
+}
+
+int lbm_hip_profile_begin(void) {
+  for (auto& r : g_prof) {
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
+  }
+  g_prof.clear();
+  g_prof_on = true;
+  return 0;
+}
+
+int lbm_hip_profile_end(lbm_hip_profile_entry* out, int32_t cap) {
+  g_prof_on = false;
+  std::map<std::string, lbm_hip_profile_entry> agg;
+  std::vector<std::string> order;
+  for (auto& r : g_prof) {
+    float ms = 0.f;
+    if (hipEventSynchronize(r.e1) != hipSuccess || hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) {
+      set_error("profile_end: event read failed");
+      return -1;
+    }
+    auto it = agg.find(r.name);
+    if (it == agg.end()) {
+      lbm_hip_profile_entry e{};
+      snprintf(e.name, sizeof(e.name), "%s", r.name);
+      it = agg.emplace(r.name, e).first;
+      order.push_back(r.name);
+    }
+    it->second.launches += 1;
+    it->second.total_ms += ms;
+    it->second.flops += r.flops;
+    it->second.bytes += r.bytes;
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
+  }
+  g_prof.clear();
+  int n = 0;
+  for (auto& k : order) {
+    if (out && n < cap) out[n] = agg[k];
+    ++n;
+  }
+  return n;
 }
 
 uint64_t lbm_hip_step_workspace_bytes(const lbm_hip_step_desc* d) {

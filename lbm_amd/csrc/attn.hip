@@ -87,6 +87,9 @@ int attn_readout(const AttnArgs& a, hipStream_t stream) {
   LBM_REQUIRE(a.S >= 1 && a.S <= 4096, "attn_readout: sequence length %d out of range", a.S);
   LBM_REQUIRE(a.ring_head >= 0 && a.ring_head < a.S, "attn_readout: ring head %d outside [0,%d)", a.ring_head, a.S);
   LBM_REQUIRE(a.slot_stride % 4 == 0 && a.point_stride % 4 == 0, "attn_readout: strides must be multiples of 4 floats");
+  // algorithmic traffic: the S sequence rows once, 4 per-head queries in, 4 per-head read-outs out, the masks
+  ProfScope prof("attn_readout", stream, (double)a.R * a.S * 4.0 * LBM_C * 4,
+                 (double)a.R * (4.0 * LBM_C * (a.S + 8) + (a.mask_a ? a.S : 0) + (a.mask_b ? a.S : 0)));
   hipLaunchKernelGGL(attn_readout_kernel, dim3((a.R + 3) / 4), dim3(256), 0, stream, a);
   return check_launch("attn_readout");
 }

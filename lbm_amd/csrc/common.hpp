@@ -26,6 +26,15 @@ int check_launch(const char* what);
     }                                               \
   } while (0)
 
+// ---- optional per-launch timing (lbm_hip_profile_begin / _end): HIP events on the launch stream ----
+// flops / bytes are the ALGORITHMIC figures of the launch, used for the roofline report.
+struct ProfScope {
+  ProfScope(const char* name, hipStream_t stream, double flops, double bytes);
+  ~ProfScope();
+  int slot;
+  hipStream_t stream;
+};
+
 // ---- cross-lane helpers (wave = 64 lanes) -----------------------------------------------------
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v) {

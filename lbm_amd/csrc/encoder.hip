@@ -47,6 +47,7 @@ int preprocess(const float* frames, long long frame_bstride, float* out, int B, 
   LBM_REQUIRE(out_nhwc == 0 || out_nhwc == 3 || out_nhwc == 4, "preprocess: out_nhwc must be 0, 3 or 4");
   long long blocks = ((long long)B * 3 * oh * ow + 255) / 256;
   if (blocks > 65535) blocks = 65535;
+  ProfScope prof("preprocess", stream, 0.0, 4.0 * B * 3 * ((double)H * W + (double)oh * ow));
   hipLaunchKernelGGL(preprocess_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, frames, out, B, H, W, oh, ow, frame_bstride, out_nhwc);
   return check_launch("preprocess");
 }
@@ -88,6 +89,7 @@ int upcat(const float* p1, const float* p2, const float* p3, float* out, int B, 
   LBM_REQUIRE(p1 && p2 && p3 && out && B > 0 && h % 4 == 0 && w % 4 == 0, "upcat: bad arguments");
   long long blocks = ((long long)B * h * w * 48 + 255) / 256;
   if (blocks > 65535) blocks = 65535;
+  ProfScope prof("upcat", stream, 0.0, 4.0 * B * h * w * (64.0 + 16.0 + 4.0 + 192.0));
   hipLaunchKernelGGL(upcat_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p1, p2, p3, out, B, h, w);
   return check_launch("upcat");
 }
@@ -128,6 +130,7 @@ int sample_queries(const float* tokens, long long tok_bstride, int ld, const flo
                    int net_h, int net_w, hipStream_t stream) {
   if ((long long)B * N == 0) return 0;
   LBM_REQUIRE(tokens && pts && out && ld % 4 == 0 && tok_bstride % 4 == 0, "sample_queries: bad arguments");
+  ProfScope prof("sample_queries", stream, 0.0, 4.0 * LBM_C * 5.0 * B * N);
   hipLaunchKernelGGL(sample_queries_kernel, dim3((unsigned)(((long long)B * N + 3) / 4)), dim3(256), 0, stream, tokens,
                      tok_bstride, ld, pts, out, B, N, h, w, (float)net_h, (float)net_w);
   return check_launch("sample_queries");

@@ -29,6 +29,7 @@ int offset_final(const float* hidden, const float* w3, const float* b3, const fl
                  float* pred, int R, hipStream_t stream) {
   if (R == 0) return 0;
   LBM_REQUIRE(hidden && w3 && b3 && ref && offset && pred, "offset_final: null argument");
+  ProfScope prof("offset_final", stream, 0.0, 4.0 * LBM_C * R);
   hipLaunchKernelGGL(offset_final_kernel, dim3((R + 3) / 4), dim3(256), 0, stream, hidden, w3, b3, ref, stride_px, offset, pred, R);
   return check_launch("offset_final");
 }
@@ -81,6 +82,7 @@ int state_final(const StateFinalArgs& a, hipStream_t stream) {
   LBM_REQUIRE(a.vis_mask == nullptr || (a.mem_mask && a.M >= 1 && a.ring_head >= 0 && a.ring_head < a.M),
               "state_final: bad mask description");
   LBM_REQUIRE(a.coords == nullptr || (a.ref && a.offset && a.net_w > 0 && a.net_h > 0), "state_final: coords need ref/offset");
+  ProfScope prof("state_final", stream, 0.0, 4.0 * LBM_C * a.R * 5.0);
   hipLaunchKernelGGL(state_final_kernel, dim3((a.R + 3) / 4), dim3(256), 0, stream, a);
   return check_launch("state_final");
 }

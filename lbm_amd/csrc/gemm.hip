@@ -23,6 +23,8 @@
 #include "gemm.hpp"
 #include "rows.hpp"
 
+#include <string>
+
 namespace lbm {
 
 struct GemmDev {
@@ -238,6 +240,12 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void gemm_f32_kernel(GemmDev a) {
 template <int BM, int BN, int WM, int WN, int WK, int BK, bool CONV>
 static int launch(const GemmDev& d, int batch, hipStream_t stream) {
   dim3 grid((d.N + BN - 1) / BN, (d.M + BM - 1) / BM, batch);
+  static const std::string name = std::string(CONV ? "conv_f32<" : "gemm_f32<") + std::to_string(BM) + "," + std::to_string(BN) + "," +
+                                  std::to_string(WM) + "," + std::to_string(WN) + "," + std::to_string(WK) + "," + std::to_string(BK) + ">";
+  const double mnk = (double)d.M * d.N * d.K * batch;
+  const double in_elems = CONV ? (double)d.M / (d.cHo * d.cWo) * d.cH * d.cW * (1 << d.cin_log2) : (double)d.M * d.K * batch;
+  ProfScope prof(name.c_str(), stream, 2.0 * mnk,
+                 4.0 * (in_elems + (double)d.N * d.K * (d.sW || batch == 1 ? batch : 1) + (double)d.M * d.N * batch * (d.res ? 2 : 1)));
   hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, WK, BK, CONV>), grid, dim3(WM * WN * WK * 64), 0, stream, d);
   return check_launch(CONV ? "conv_f32" : "gemm_f32");
 }
@@ -325,6 +333,7 @@ int maxpool3x3s2_nhwc(const float* x, float* y, int B, int H, int W, int C, hipS
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   long long blocks = ((long long)B * Ho * Wo * (C / 4) + 255) / 256;
   if (blocks > 65535) blocks = 65535;
+  ProfScope prof("maxpool3x3s2", stream, 0.0, 4.0 * B * C * ((double)H * W + (double)Ho * Wo));
   hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, y, B, H, W, C / 4, Ho, Wo);
   return check_launch("maxpool3x3s2");
 }

@@ -115,6 +115,10 @@ int msda_sample(const MsdaArgs& a, hipStream_t stream) {
   }
   LBM_REQUIRE(a.B == 1 || a.v_batch_stride >= tokens * a.ldv - (a.ldv - LBM_C), "msda_sample: batch stride smaller than one value map");
   const bool explicit_mode = a.loc != nullptr;
+  // algorithmic traffic per query: 4 heads x 4 levels x P points x 4 taps x 64 channels read (L2/MALL-resident maps),
+  // one 256-channel row written
+  ProfScope prof("msda_sample", stream, (double)R * a.k * 16.0 * a.P * 4 * 64 * 2,
+                 (double)R * a.k * (16.0 * a.P * 4 * 64 * 4 + 4.0 * LBM_C));
   if (explicit_mode) {
     LBM_REQUIRE(a.attw != nullptr && a.k == 1, "msda_sample: explicit mode needs attw and k == 1");
     hipLaunchKernelGGL(msda_sample_kernel<true>, dim3((unsigned)R), dim3(256), 0, stream, a);

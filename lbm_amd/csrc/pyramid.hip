@@ -53,6 +53,7 @@ int pyramid_pool(float* tokens, int B, int h, int w, hipStream_t stream) {
   const int L = P0 + P0 / 4 + P0 / 16 + P0 / 64;
   long long blocks = ((long long)B * (L - P0) + 3) / 4;
   if (blocks > 16384) blocks = 16384;
+  ProfScope prof("pyramid_pool", stream, 0.0, 4.0 * LBM_C * B * ((double)P0 + (L - P0)));
   hipLaunchKernelGGL(pyramid_pool_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, tokens, B, h, w, L);
   return check_launch("pyramid_pool");
 }
@@ -145,7 +146,10 @@ int corr_maps(const float* tokens, float* inv_norm, float* F, const float* wmix_
   long long rows = (long long)B * L;
   long long blocks = (rows + 3) / 4;
   if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(inv_norm_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, tokens, inv_norm, rows);
+  {
+    ProfScope prof("inv_norm", stream, 0.0, 4.0 * LBM_C * rows);
+    hipLaunchKernelGGL(inv_norm_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, tokens, inv_norm, rows);
+  }
   if (check_launch("inv_norm")) return -1;
   CorrMapArgs a;
   a.tok = tokens; a.inv = inv_norm; a.F = F; a.n_layers = n_layers; a.B = B; a.h = h; a.w = w; a.L = L;
@@ -153,6 +157,7 @@ int corr_maps(const float* tokens, float* inv_norm, float* F, const float* wmix_
     for (int l = 0; l < 4; ++l) a.wmix[i][l] = i < n_layers ? wmix_host[i * 4 + l] : 0.f;
   blocks = ((long long)B * P0 + 3) / 4;
   if (blocks > 16384) blocks = 16384;
+  ProfScope prof("corr_maps", stream, 0.0, 4.0 * LBM_C * B * ((double)L + (double)n_layers * P0));
   hipLaunchKernelGGL(corr_maps_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
   return check_launch("corr_maps");
 }
@@ -238,6 +243,7 @@ int topk_rows(const float* corr, long long ld, int P, int k, int rows, int grid_
   LBM_REQUIRE(ld % 4 == 0 && ((uintptr_t)corr & 15) == 0, "topk_rows: rows must be 16-byte aligned");
   dim3 grid((rows + 3) / 4), block(256);
   const float cell = (float)stride_px;
+  ProfScope prof("topk_rows", stream, 0.0, 4.0 * rows * ((double)P + 4.0 * k));
   if (k == 1)
     hipLaunchKernelGGL(topk_rows_kernel<1>, grid, block, 0, stream, corr, ld, P, k, rows, grid_w, cell, idx_out, ref_out, val_out);
   else if (k <= 4)

@@ -47,6 +47,7 @@ int layernorm_rows(const float* X, const float* gamma, const float* beta, float*
   if (rows == 0) return 0;
   LBM_REQUIRE(X && gamma && beta && Y && rows > 0, "layernorm_rows: null argument");
   LBM_REQUIRE(keep == nullptr || fallback != nullptr, "layernorm_rows: keep mask needs a fallback");
+  ProfScope prof("layernorm_rows", stream, 0.0, 4.0 * LBM_C * rows * (2.0 + (Yn ? 1 : 0)));
   hipLaunchKernelGGL(layernorm_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, X, gamma, beta, Y, rows, keep,
                      fallback, Yn);
   return check_launch("layernorm_rows");
@@ -57,6 +58,7 @@ int l2norm_rows(const float* X, long long ldx, float* Y, long long ldy, long lon
   LBM_REQUIRE(X && Y && ldx % 4 == 0 && ldy % 4 == 0, "l2norm_rows: bad arguments");
   long long blocks = (rows + 3) / 4;
   if (blocks > 8192) blocks = 8192;
+  ProfScope prof("l2norm_rows", stream, 0.0, 8.0 * LBM_C * rows);
   hipLaunchKernelGGL(l2norm_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, X, ldx, Y, ldy, rows);
   return check_launch("l2norm_rows");
 }

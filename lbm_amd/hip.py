@@ -25,6 +25,7 @@ EXPORTS = (
     "lbm_hip_attn_readout", "lbm_hip_pyramid", "lbm_hip_corr_maps", "lbm_hip_topk", "lbm_hip_msda_sample",
     "lbm_hip_preprocess", "lbm_hip_upcat", "lbm_hip_sample_queries", "lbm_hip_step_workspace_bytes",
     "lbm_hip_track_step", "lbm_hip_step_workspace_offset", "lbm_hip_conv2d_nhwc", "lbm_hip_maxpool3x3s2_nhwc",
+    "lbm_hip_profile_begin", "lbm_hip_profile_end",
 )
 
 
@@ -67,6 +68,11 @@ class StepDesc(C.Structure):
                 ("ref_points", C.c_void_p * MAX_LAYERS), ("topk_idx", C.c_void_p * MAX_LAYERS),
                 ("ref_rho", C.c_void_p * MAX_LAYERS), ("corr", C.c_void_p * MAX_LAYERS),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_uint64)]
+
+
+class ProfileEntry(C.Structure):
+    _fields_ = [("name", C.c_char * 96), ("launches", C.c_int64), ("total_ms", C.c_double), ("flops", C.c_double),
+                ("bytes", C.c_double)]
 
 
 _lib: Optional[C.CDLL] = None
@@ -120,6 +126,7 @@ def load() -> C.CDLL:
     lib.lbm_hip_track_step.argtypes = [C.POINTER(StepDesc), C.c_void_p]
     lib.lbm_hip_conv2d_nhwc.argtypes = [C.c_void_p] * 6 + [C.c_int32] * 11 + [C.c_void_p]
     lib.lbm_hip_maxpool3x3s2_nhwc.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p]
+    lib.lbm_hip_profile_end.argtypes = [C.POINTER(ProfileEntry), C.c_int32]
     _lib = lib
     return lib
 
@@ -150,6 +157,21 @@ def _p(t: Optional[torch.Tensor], dtype=torch.float32) -> Optional[int]:
 
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
+
+
+def profile_begin() -> None:
+    """Bracket every kernel launch of the library with HIP events until profile_end()."""
+    _check(load().lbm_hip_profile_begin(), "lbm_hip_profile_begin")
+
+
+def profile_end() -> List[dict]:
+    """Per-kernel totals since profile_begin(): name, launches, total_ms, algorithmic flops and bytes."""
+    buf = (ProfileEntry * 128)()
+    n = load().lbm_hip_profile_end(buf, 128)
+    if n < 0:
+        raise HipError("lbm_hip_profile_end: " + load().lbm_hip_last_error().decode())
+    return [dict(name=buf[i].name.decode(), launches=int(buf[i].launches), total_ms=float(buf[i].total_ms),
+                 flops=float(buf[i].flops), bytes=float(buf[i].bytes)) for i in range(min(n, 128))]
 
 
 # ----------------------------------------------------------------------------------------------

@@ -163,13 +163,12 @@ def main():
                 p["per_step_us"] = 1e3 * p["total_ms"] / nprof
 
     # results travel over RCCL only here (gather of the last frame's tracks), as the north star asks
-    if dist is not None:
-        res = torch.cat([coords, vis.float().unsqueeze(-1), rho.unsqueeze(-1)], -1).contiguous()
-        gathered = [torch.empty_like(res) for _ in range(world)] if rank == 0 else None
-        dist.gather(res, gathered, dst=0)
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    from lbm_amd.sharding import gather_tracks, max_over_ranks
+    res = torch.cat([coords, vis.float().unsqueeze(-1), rho.unsqueeze(-1)], -1).contiguous()     # (B, N, 4)
+    gathered = gather_tracks(res, B * world, dst=0)
+    if rank == 0:
+        assert gathered.shape == (B * world, N, 4) and bool(torch.isfinite(gathered).all())
+    elapsed = max_over_ranks(elapsed, device)
 
     if rank == 0:
         total_pf = float(B) * N * world * args.steps

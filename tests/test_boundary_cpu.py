@@ -1,0 +1,85 @@
+"""Host-side mirror of the reference interface: import paths, config merge rule, video/query loader, state-dict layout."""
+import argparse
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+def test_reference_import_paths_resolve():
+    from lbm.models import LBM
+    from lbm.models.lbm_online import LBM_online, LBM_export
+    from lbm.models.lbm.lbm import LBM as LBM2
+    from lbm.models.lbm.transformer import LBMTransformer, LBMTransformerLayer, MLP
+    from lbm.models.lbm.backbone import Backbone
+    from lbm.models.lbm.msdeformattn import MultiScaleDeformableAttention, multi_scale_deformable_attn_pytorch
+    from lbm.utils.train_utils import fix_random_seeds
+    from lbm.utils.eval_utils import load_config
+    from lbm.utils.demo_utils import load_video
+    from lbm.utils.coord_utils import indices_to_coords
+    assert LBM is LBM2 and issubclass(LBM_online, LBM)
+    fix_random_seeds(42)
+
+
+def test_load_config_merge_rule(tmp_path):
+    from lbm.utils.eval_utils import load_config
+    p = tmp_path / "demo.yaml"
+    p.write_text("input_size: [384, 512]\nmemory_size: 12\nstride: 4\nvideo_path: 'data/demo.mp4'\n")
+    args = argparse.Namespace(config_path=str(p), memory_size=20, video_path=None, grid_size=32)
+    cfg = load_config(args)
+    assert cfg.memory_size == 20 and cfg.video_path == "data/demo.mp4" and cfg.grid_size == 32 and cfg.input_size == [384, 512]
+    assert load_config(argparse.Namespace(config_path=str(tmp_path / "missing.yaml"))) == {}
+
+
+def test_load_video_grid_rule_and_layout(tmp_path):
+    from lbm.utils.demo_utils import load_video
+    frames, video, pts = load_video("synthetic:3:48:64", grid_query=True, grid_size=3)
+    assert len(frames) == 3 and frames[0].shape == (48, 64, 3) and frames[0].dtype == np.uint8
+    assert video.shape == (1, 3, 3, 48, 64) and video.dtype == torch.float32
+    assert float(video.min()) >= 0 and float(video.max()) <= 255
+    # BGR frames, RGB tensor (demo_utils.py:127-131)
+    assert np.array_equal(frames[1][:, :, ::-1], video[0, 1].permute(1, 2, 0).numpy().astype(np.uint8))
+    want = [(int(i * 64 / 4), int(j * 48 / 4)) for i in range(1, 4) for j in range(1, 4)]
+    assert pts.tolist() == [[float(a), float(b)] for a, b in want]
+    # no click / grid -> zero points, as benchmark_torch.py:47 gets
+    assert load_video("synthetic:2:48:64")[2].shape == (0, 2)
+    np.save(tmp_path / "clip.npy", np.zeros((2, 8, 8, 3), dtype=np.uint8))
+    assert load_video(str(tmp_path / "clip.npy"))[1].shape == (1, 2, 3, 8, 8)
+    with pytest.raises(FileNotFoundError):
+        load_video(str(tmp_path / "nope"))
+
+
+def test_state_dict_has_the_lbm_pt_key_layout():
+    """232 transformer keys, the ResNet-18 stem..layer3 keys, proj/fusion/pos-emb; strict load."""
+    from lbm_amd.config import LBMConfig
+    from lbm_amd.synth import synthetic_state_dict
+    from lbm.models.lbm_online import LBM_online
+    m = LBM_online(LBMConfig().to_namespace())
+    sd = m.state_dict()
+    tkeys = [k for k in sd if k.startswith("transformer.")]
+    assert len(tkeys) == 232
+    assert sd["transformer.layers.0.collision_time_emb"].shape == (1, 13, 256)
+    assert sd["transformer.layers.2.lattice_attention.sampling_offsets.weight"].shape == (288, 256)
+    assert sd["transformer.collision_mem_layer.attention_weights.weight"].shape == (64, 256)
+    assert sd["transformer.layers.1.corr_conv.weight"].shape == (1, 4, 1, 1)
+    assert sd["transformer.start_levels"].tolist() == [0, 12288, 15360, 16128]
+    assert sd["backbone.layer1.0.weight"].shape == (64, 3, 7, 7)
+    assert sd["backbone.layer2.0.downsample.0.weight"].shape == (128, 64, 1, 1)
+    assert sd["backbone.layer3.1.bn2.num_batches_tracked"].dtype == torch.int64
+    assert sd["backbone.fusion.0.weight"].shape == (256, 192, 1, 1)
+    assert sd["backbone.frame_pos_embedding"].shape == (1, 256, 96, 128)
+    n_tr = sum(v.numel() for k, v in m.transformer.named_parameters())
+    assert n_tr == 11_814_726
+    m.load_state_dict(synthetic_state_dict(m, 1), strict=True)
+    # ckpt_converter.py:55 layout: {'model': state_dict}
+    ckpt = {"model": {("module." + k): v for k, v in sd.items()}}
+    stripped = {k[len("module."):]: v for k, v in ckpt["model"].items()}
+    m.load_state_dict(stripped, strict=True)
+
+
+def test_indices_to_coords_host_version(golden):
+    from lbm.utils.coord_utils import indices_to_coords
+    gold = golden("coords")
+    got = indices_to_coords(torch.from_numpy(gold["idx"]), [384, 512], 4)
+    assert np.array_equal(got.numpy(), gold["coords"])

@@ -379,3 +379,88 @@ def test_set_memory_size_against_oracle(hip):
                                 cu["queried"])
     _cmp(got[3], want[3], rtol=0, atol=LOGIT_TOL)
     _cmp(got[2], want[2], rtol=0, atol=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the reference's callers, restated: tools/demo_grid.py:29-51 and tools/benchmark_torch.py:42-76 through lbm.* paths
+# ---------------------------------------------------------------------------------------------------------------
+
+def test_demo_grid_style_flow_through_reference_import_paths(hip, tmp_path):
+    import argparse
+    from lbm.models.lbm_online import LBM_online
+    from lbm.utils.train_utils import fix_random_seeds
+    from lbm.utils.eval_utils import load_config
+    from lbm.utils.demo_utils import load_video
+    from lbm_amd.synth import synthetic_state_dict
+    cfgp = tmp_path / "demo.yaml"
+    cfgp.write_text("input_size: [384, 512]\nN: 256\nT: 24\nstride: 4\nnum_layers: 3\nembed_dim: 256\nnum_heads: 4\n"
+                    "num_levels: 4\nnum_neighbors: 9\ntop_k_regions: 9\ndropout: 0.1\nmemory_size: 12\nlambda_cls: 3.0\n"
+                    "lambda_vis: 1.0\nlambda_reg: 1.0\nlambda_unc: 1.0\nlambda_ref: 1.0\nloss_after_query: false\n")
+    fix_random_seeds(42)
+    config = load_config(argparse.Namespace(config_path=str(cfgp), video_path="synthetic:4:240:320", grid_size=6))
+    model = LBM_online(config).cuda().eval()
+    ckpt = tmp_path / "lbm.pt"
+    torch.save({"model": synthetic_state_dict(model, 42)}, ckpt)
+    model.load_state_dict(torch.load(ckpt, weights_only=True)["model"], strict=True)
+    frames, video, query_points = load_video(config.video_path, grid_query=True, grid_size=config.grid_size)
+    video, query_points = video.cuda(), query_points.cuda()
+    traj = []
+    with torch.no_grad():
+        model.init(query_points, video[:, 0])
+        for t in range(1, video.shape[1]):
+            coord, vis, rho, f_t = model.online_forward(video[:, t])
+            assert coord.shape == (36, 2) and vis.shape == (36,) and vis.dtype == torch.bool and rho.shape == (36,)
+            assert f_t.shape == (1, 256, 96, 128)
+            assert bool(torch.isfinite(coord).all()) and float(rho.min()) > 0 and float(rho.max()) < 1
+            traj.append(coord)
+    assert model.t == 3 and model.N == 36
+    # benchmark_torch.py as committed passes zero points: online_forward must raise (it is caught there)
+    model2 = LBM_online(config).cuda().eval()
+    with torch.no_grad():
+        model2.init(torch.zeros(0, 2, device="cuda"), video[:, 0])
+        with pytest.raises(Exception):
+            model2.online_forward(video[:, 1])
+
+
+def test_update_adds_and_removes_points_like_the_reference(hip):
+    """LBM_online.update (lbm_online.py:48-112): kept points carry their query and memories, new points start
+    with empty (all-masked) memories; checked against the oracle's state after the same edit."""
+    from lbm_amd.synth import synthetic_video, grid_queries
+    model, sd = _online(dict(input_size=(96, 128), memory_size=4))
+    g = ref.Geometry(size=(96, 128), memory_size=4)
+    video = synthetic_video(5, 120, 160, seed=8)
+    pts = grid_queries(120, 160, 3)                                       # 9 points
+    oracle = ref.RefOnline(sd, g)
+    with torch.no_grad():
+        model.init(pts.cuda(), video[:, 0].cuda())
+        oracle.init(pts, video[:, 0])
+        for t in (1, 2):
+            _, _, _, f_t = model.online_forward(video[:, t].cuda())
+            ofeat = oracle.online_forward(video[:, t])[3]
+        # drop points 1 and 4, append two new ones sampled on the current frame
+        remove = torch.zeros(9, dtype=torch.bool)
+        remove[[1, 4]] = True
+        new_pts = torch.tensor([[33.0, 71.0], [120.0, 20.0]])
+        all_pts = torch.cat([pts[~remove], new_pts], 0)                   # 9 points again
+        upd = torch.zeros(9, dtype=torch.bool)
+        upd[7:] = True
+        model.update(all_pts.cuda(), f_t, upd.cuda(), remove.cuda())
+        # oracle: the same edit on its state (lbm_online.py:84-110)
+        st = oracle.state
+        scaled = new_pts.clone()
+        scaled[:, 0] = scaled[:, 0] / 160 * 128
+        scaled[:, 1] = scaled[:, 1] / 120 * 96
+        q_new = ref.sample_queries(ofeat, scaled, g)
+        nst = ref.fresh_state(torch.zeros(1, 9, 256), g)
+        nst.query[:, :7] = st.query[:, ~remove]
+        nst.query[:, upd] = q_new
+        for name in ("collision", "stream", "vis_mask", "mem_mask"):
+            getattr(nst, name)[:, :7] = getattr(st, name)[:, ~remove]
+        oracle.state = nst
+        _cmp(model.query, nst.query, rtol=2e-3, atol=2e-3)
+        _cmp(model.stream_dist, nst.stream, rtol=2e-3, atol=2e-3)
+        assert (model.mem_mask.cpu() == nst.mem_mask).all() and (model.vis_mask.cpu() == nst.vis_mask).all()
+        for t in (3, 4):
+            c, v, r, _ = model.online_forward(video[:, t].cuda())
+            oc = oracle.online_forward(video[:, t])[0]
+            _cmp(c, oc, rtol=0, atol=COORD_TOL)

@@ -42,8 +42,30 @@ typedef struct {
   int32_t act, batch;
   int64_t sX, sW, sB, sY, sR;
   const float* ln_gamma; const float* ln_beta; const uint8_t* keep; const float* fallback; float* Yn;
+  /* split-precision path (see lbm_hip_split_planes): when both are non-NULL, W is ignored and the product runs on
+   * the f16 matrix cores with fp32-grade accuracy (three MFMAs per block, fp32 accumulate); ldw % 8 == 0.       */
+  const void* W_hi; const void* W_lo;
 } lbm_hip_linear_desc;
 int lbm_hip_linear(const lbm_hip_linear_desc* d, lbm_stream_t stream);
+
+/* fp32 x[n] -> two f16 planes with x = hi + lo * 2^-11 (hi = f16(x), lo = f16((x - hi) * 2^11); |x| clamped to
+ * 65000).  This is the operand format of the split-precision GEMM / convolution: weights are split once per
+ * model, per-frame operands (correlation maps) by their producing kernel.  n % 4 == 0.                         */
+int lbm_hip_split_planes(const float* x, void* hi, void* lo, int64_t n, lbm_stream_t stream);
+
+/* Dense block with BOTH operands pre-split (f16 hi plane at the pointer, lo plane `*_plane` elements further):
+ * Y = act(A . B^T + bias) + res_scale * RES[(m / res_div) % res_mod], written as fp32 (Y) and/or as split planes
+ * (Ys) for the next product.  Operands are staged by LDS-DMA, three f16 MFMAs per 32x32x16 block, fp32 accumulate.
+ * K % 32 == 0; lda, ldb, planes and batch strides multiples of 8; act / residual as in lbm_hip_linear.        */
+typedef struct {
+  const void* A; const void* B; int64_t a_plane, b_plane;
+  const float* bias; float* Y; void* Ys; int64_t ys_plane; const float* res;
+  int32_t M, N, K, lda, ldb, ldy, ldys, ldres, res_div, res_mod;
+  float res_scale;
+  int32_t act, batch;
+  int64_t sA, sB, sBias, sY, sYs, sR;
+} lbm_hip_linear_ss_desc;
+int lbm_hip_linear_ss(const lbm_hip_linear_ss_desc* d, lbm_stream_t stream);
 
 /* Row-wise LayerNorm over C = 256 (+ optional keep/fallback select and L2-normalised copy).
  * Replaces nn.LayerNorm (transformer.py:31,163,...) and the valid-row scatter of transformer.py:279,301. */
@@ -111,10 +133,11 @@ int lbm_hip_sample_queries(const float* tokens, int64_t tok_bstride, int32_t ld,
 /* ResNet-18 body (backbone.py:20-26, 49-51; torchvision BasicBlock) on pixel-major activations:
  * Y[b,oy,ox,:] = relu?(conv(X)[...] + bias (+ res)), BatchNorm folded into W/bias by the caller.
  * X [B,H,W,Cin] with Cin a power of two >= 4 (the RGB stem is padded to 4 channels); W [Cout, ldw] with
- * columns ordered (ky, kx, ci) and zero-padded to a multiple of 32 (ldw = 0 selects exactly that);
- * `reserved` must be NULL.  maxpool: 3x3 / stride 2 / pad 1 (backbone.py:23).                    */
-int lbm_hip_conv2d_nhwc(const float* X, const float* W, const float* bias, const float* res, float* Y,
-                        const void* reserved, int32_t B, int32_t H, int32_t Wd, int32_t Cin, int32_t Cout,
+ * columns ordered (ky, kx, ci) and zero-padded to a multiple of 32 (ldw = 0 selects exactly that).
+ * W_lo == NULL: W is fp32 (exact fp32 MFMA).  W_lo != NULL: W is the f16 hi plane and W_lo the f16 lo plane of
+ * the same packed matrix (split-precision path).  maxpool: 3x3 / stride 2 / pad 1 (backbone.py:23).        */
+int lbm_hip_conv2d_nhwc(const float* X, const void* W, const float* bias, const float* res, float* Y,
+                        const void* W_lo, int32_t B, int32_t H, int32_t Wd, int32_t Cin, int32_t Cout,
                         int32_t kh, int32_t kw, int32_t stride, int32_t pad, int32_t relu, int32_t ldw,
                         lbm_stream_t stream);
 int lbm_hip_maxpool3x3s2_nhwc(const float* x, float* y, int32_t B, int32_t H, int32_t W, int32_t C,
@@ -192,6 +215,12 @@ typedef struct {
   /* weights */
   const float* const* weights;          /* HOST array of DEVICE pointers, LBM_W_* layout */
   int32_t n_weights;
+  /* precision 0: every contraction on the exact-fp32 MFMA (weights[] are fp32 matrices).
+   * precision 1: contractions on the f16 matrix cores with split operands (fp32-grade, see lbm_hip_split_planes):
+   *   for every MATRIX entry of the table, weights[i] is its f16 hi plane and weights_lo[i] its f16 lo plane;
+   *   vectors (biases, LayerNorm, time embeddings) and LBM_W_LAYER_RHO_W stay fp32 in weights[].                */
+  int32_t precision;
+  const void* const* weights_lo;
   /* inputs */
   const float* tokens;                  /* [B, L, 256] pyramid (levels filled) */
   const float* query;                   /* [B, N, 256] initial point tokens */
@@ -233,6 +262,9 @@ typedef struct {
 } lbm_hip_profile_entry;
 int lbm_hip_profile_begin(void);
 int lbm_hip_profile_end(lbm_hip_profile_entry* out, int32_t cap);
+
+/* tuning / debugging knob (process-wide): key 1 = force the split-GEMM tiling (0 auto, 1..n see gemm16.hip) */
+int lbm_hip_debug_set(int32_t key, int32_t value);
 
 /* debugging aid for parity tests: byte offset of a named intermediate inside the workspace, or -1 */
 int64_t lbm_hip_step_workspace_offset(const lbm_hip_step_desc* d, const char* name);

@@ -66,7 +66,7 @@ struct StepLayout {
     const char* name;
     unsigned long long off, bytes;
   };
-  Item items[32];
+  Item items[48];
   int n = 0;
   unsigned long long total = 0;
   unsigned long long add(const char* name, unsigned long long bytes) {
@@ -86,6 +86,7 @@ static int build_layout(const lbm_hip_step_desc* d, StepLayout& lay) {
   LBM_REQUIRE(d != nullptr, "step: null descriptor");
   LBM_REQUIRE(d->B >= 1 && d->N >= 0 && d->M >= 1 && d->M <= 4096, "step: bad B/N/M (%d, %d, %d)", d->B, d->N, d->M);
   LBM_REQUIRE(d->n_layers >= 1 && d->n_layers <= LBM_HIP_MAX_LAYERS, "step: n_layers=%d out of range", d->n_layers);
+  LBM_REQUIRE(d->precision == 0 || d->precision == 1, "step: precision must be 0 (fp32 MFMA) or 1 (split f16 MFMA)");
   LBM_REQUIRE(d->stride == 4 && d->net_h % 32 == 0 && d->net_w % 32 == 0 && d->net_h > 0 && d->net_w > 0,
               "step: network input %dx%d (stride %d) must be a multiple of 32 with stride 4", d->net_h, d->net_w, d->stride);
   int kmax = 1;
@@ -124,8 +125,28 @@ static int build_layout(const lbm_hip_step_desc* d, StepLayout& lay) {
   lay.add("lb", (unsigned long long)lay.Q * LBM_C * f);
   lay.add("pred", (unsigned long long)lay.R * 2 * f);
   lay.add("coll_tok", (unsigned long long)lay.R * LBM_C * f);
+  lay.add("pre", (unsigned long long)lay.R * LBM_C * f);
+  lay.add("preq", (unsigned long long)lay.Q * LBM_C * f);
+  lay.add("hidR", (unsigned long long)lay.R * LBM_C * f);
+  if (d->precision == 1) {   // split twins (two f16 planes = the same number of bytes as the fp32 tensor)
+    lay.add("tok_s", (unsigned long long)d->B * lay.L * LBM_C * f);
+    lay.add("q_s", (unsigned long long)lay.R * LBM_C * f);
+    lay.add("x0_s", (unsigned long long)lay.R * LBM_C * f);
+    lay.add("x1_s", (unsigned long long)lay.R * LBM_C * f);
+    lay.add("ta_s", (unsigned long long)lay.R * LBM_C * f);
+    lay.add("tb_s", (unsigned long long)lay.R * LBM_C * f);
+    lay.add("tc_s", (unsigned long long)lay.R * LBM_C * f);
+    lay.add("la_s", (unsigned long long)lay.Q * LBM_C * f);
+  }
   return 0;
 }
+
+// A tensor view used by the step: fp32 rows and/or the same values as split f16 planes (hi at `s`, lo at s + plane).
+struct TV {
+  float* f = nullptr;
+  void* s = nullptr;
+  long long plane = 0;
+};
 
 struct Step {
   const lbm_hip_step_desc* d;
@@ -133,56 +154,87 @@ struct Step {
   hipStream_t s;
   char* ws;
   int h, w;
+  bool split;   // precision 1: dense contractions on the f16 matrix cores with split operands
   template <typename T>
   T* buf(const char* name) {
     return reinterpret_cast<T*>(ws + lay.find(name));
   }
   const float* W(int idx) const { return d->weights[idx]; }
+  TV tv(const char* fname, const char* sname, long long elems) {
+    TV t;
+    if (fname) t.f = buf<float>(fname);
+    if (split && sname) {
+      t.s = buf<char>(sname);
+      t.plane = elems;
+    }
+    return t;
+  }
 
-  int linear(const float* X, int ldx, const float* Wt, const float* b, float* Y, int ldy, int M, int N, int K, int act = ACT_NONE,
-             const float* res = nullptr, int res_div = 1, float res_scale = 1.f, const float* g = nullptr, const float* be = nullptr,
-             const uint8_t* keep = nullptr, const float* fallback = nullptr, float* Yn = nullptr) {
-    GemmArgs a;
-    a.X = X; a.ldx = ldx; a.W = Wt; a.ldw = K; a.bias = b; a.Y = Y; a.ldy = ldy; a.M = M; a.N = N; a.K = K; a.act = act;
-    a.res = res; a.ldres = LBM_C; a.res_div = res_div; a.res_scale = res_scale;
-    a.ln_gamma = g; a.ln_beta = be; a.keep = keep; a.fallback = fallback; a.Yn = Yn;
-    return gemm(a, s);
+  // Y = act(X · W[wi]ᵀ + W[bi]) + res_scale · res[(m / res_div)]   (Y.f fp32 and / or Y.s split, as the view asks)
+  int linear(const TV& X, int ldx, int wi, int bi, const TV& Y, int ldy, int M, int N, int K, int act = ACT_NONE,
+             const float* res = nullptr, int res_div = 1, float res_scale = 1.f) {
+    if (!split) {
+      GemmArgs a;
+      a.X = X.f; a.ldx = ldx; a.W = W(wi); a.ldw = K; a.bias = bi >= 0 ? W(bi) : nullptr; a.Y = Y.f; a.ldy = ldy;
+      a.M = M; a.N = N; a.K = K; a.act = act; a.res = res; a.ldres = LBM_C; a.res_div = res_div; a.res_scale = res_scale;
+      return gemm(a, s);
+    }
+    GemmSSArgs a;
+    a.A = X.s; a.a_plane = X.plane; a.lda = ldx;
+    a.B = d->weights[wi]; a.b_plane = (const char*)d->weights_lo[wi] - (const char*)d->weights[wi];
+    LBM_REQUIRE(a.b_plane % 2 == 0, "step: weight planes misaligned");
+    a.b_plane /= 2;
+    a.ldb = K; a.bias = bi >= 0 ? W(bi) : nullptr;
+    a.Y = Y.f; a.ldy = ldy; a.Ys = Y.s; a.ys_plane = Y.plane; a.ldys = ldy;
+    a.M = M; a.N = N; a.K = K; a.act = act; a.res = res; a.ldres = LBM_C; a.res_div = res_div; a.res_scale = res_scale;
+    return gemm_ss(a, s);
+  }
+
+  int ln(const float* X, int gi, int bi, const TV& Y, int rows, const uint8_t* keep = nullptr, const float* fallback = nullptr,
+         const TV* Yn = nullptr) {
+    RowsOut o;
+    o.Y = Y.f; o.Ys = Y.s; o.ys_plane = Y.plane;
+    if (Yn) {
+      o.Yn = Yn->f; o.Yns = Yn->s; o.yns_plane = Yn->plane;
+    }
+    return layernorm_rows_ex(X, W(gi), W(bi), rows, keep, fallback, o, s);
   }
 
   // memory / lattice-update attention block: x_in [R,256] -> x_out [R,256]
-  int attn_block(int wb, const float* x_in, float* x_out, const float* seq, long long point_stride, int S, int ring_head,
-                 bool masked, float* Yn) {
+  int attn_block(int wb, const TV& x_in, const TV& x_out, const float* seq, long long point_stride, int S, int ring_head,
+                 bool masked, const TV* Yn) {
     const int R = (int)lay.R;
-    float* U = buf<float>("U");
-    float* mbar = buf<float>("mbar");
-    float* hid = buf<float>("hid");
-    float* y = buf<float>("tc");
+    TV U;   U.f = buf<float>("U");
+    TV mbar = split ? TV{nullptr, buf<char>("mbar"), (long long)R * 1024} : TV{buf<float>("mbar"), nullptr, 0};
+    TV hid = split ? TV{nullptr, buf<char>("hid"), (long long)R * 1024} : TV{buf<float>("hid"), nullptr, 0};
+    TV pre; pre.f = buf<float>("pre");
+    TV y = tv("tc", "tc_s", (long long)R * LBM_C);
     uint8_t* valid = masked ? buf<uint8_t>("valid") : nullptr;
-    if (linear(x_in, LBM_C, W(wb + LBM_W_ATTN_G), W(wb + LBM_W_ATTN_GB), U, 1024, R, 1024, LBM_C)) return -1;
+    if (linear(x_in, LBM_C, wb + LBM_W_ATTN_G, wb + LBM_W_ATTN_GB, U, 1024, R, 1024, LBM_C)) return -1;
     AttnArgs a;
-    a.U = U; a.seq = seq; a.point_stride = point_stride; a.slot_stride = LBM_C; a.S = S; a.ring_head = ring_head;
+    a.U = U.f; a.seq = seq; a.point_stride = point_stride; a.slot_stride = LBM_C; a.S = S; a.ring_head = ring_head;
     a.temb = masked ? W(wb + LBM_W_ATTN_TEMB) : nullptr;
     a.mask_a = masked ? d->vis_mask : nullptr;
     a.mask_b = masked ? d->mem_mask : nullptr;
-    a.out = mbar; a.valid = valid; a.R = R;
+    a.out = mbar.f; a.out_s = mbar.s; a.out_plane = mbar.plane; a.valid = valid; a.R = R;
     if (attn_readout(a, s)) return -1;
-    if (linear(mbar, 1024, W(wb + LBM_W_ATTN_HM), W(wb + LBM_W_ATTN_HB), y, LBM_C, R, LBM_C, 1024, ACT_NONE, x_in, 1, 1.f,
-               W(wb + LBM_W_ATTN_LN1G), W(wb + LBM_W_ATTN_LN1B)))
-      return -1;
-    if (linear(y, LBM_C, W(wb + LBM_W_ATTN_F1W), W(wb + LBM_W_ATTN_F1B), hid, 1024, R, 1024, LBM_C, ACT_GELU)) return -1;
-    return linear(hid, 1024, W(wb + LBM_W_ATTN_F2W), W(wb + LBM_W_ATTN_F2B), x_out, LBM_C, R, LBM_C, 1024, ACT_NONE, y, 1, 1.f,
-                  W(wb + LBM_W_ATTN_LN2G), W(wb + LBM_W_ATTN_LN2B), valid, x_in, Yn);
+    if (linear(mbar, 1024, wb + LBM_W_ATTN_HM, wb + LBM_W_ATTN_HB, pre, LBM_C, R, LBM_C, 1024, ACT_NONE, x_in.f, 1, 1.f)) return -1;
+    if (ln(pre.f, wb + LBM_W_ATTN_LN1G, wb + LBM_W_ATTN_LN1B, y, R)) return -1;
+    if (linear(y, LBM_C, wb + LBM_W_ATTN_F1W, wb + LBM_W_ATTN_F1B, hid, 1024, R, 1024, LBM_C, ACT_GELU)) return -1;
+    if (linear(hid, 1024, wb + LBM_W_ATTN_F2W, wb + LBM_W_ATTN_F2B, pre, LBM_C, R, LBM_C, 1024, ACT_NONE, y.f, 1, 1.f)) return -1;
+    return ln(pre.f, wb + LBM_W_ATTN_LN2G, wb + LBM_W_ATTN_LN2B, x_out, R, valid, x_in.f, Yn);
   }
 
   // deformable block: token x [R,256] (replicated k times) sampled at ref [R,k,2] -> out [R*k,256]
-  int msda_block(int wb, int vmap, int P, const float* x, const float* ref, int k, float* out) {
+  int msda_block(int wb, int vmap, int P, const TV& x, const float* ref, int k, const TV& out) {
     const int R = (int)lay.R, Q = R * k;
-    float* offlog = buf<float>("offlog");
-    float* samp = buf<float>("samp");
-    float* la = buf<float>("la");
-    float* hid = buf<float>("hid");
+    TV offlog; offlog.f = buf<float>("offlog");
+    TV samp = split ? TV{nullptr, buf<char>("samp"), (long long)Q * LBM_C} : TV{buf<float>("samp"), nullptr, 0};
+    TV hid = split ? TV{nullptr, buf<char>("hid"), (long long)Q * 1024} : TV{buf<float>("hid"), nullptr, 0};
+    TV pre; pre.f = buf<float>("preq");
+    TV la = tv("la", "la_s", (long long)Q * LBM_C);
     const int ncol = 48 * P;
-    if (linear(x, LBM_C, W(wb + LBM_W_MSDA_OLW), W(wb + LBM_W_MSDA_OLB), offlog, ncol, R, ncol, LBM_C)) return -1;
+    if (linear(x, LBM_C, wb + LBM_W_MSDA_OLW, wb + LBM_W_MSDA_OLB, offlog, ncol, R, ncol, LBM_C)) return -1;
     MsdaArgs m;
     m.value = buf<float>("value") + (long long)vmap * LBM_C;
     m.ldv = lay.n_vmaps * LBM_C;
@@ -193,66 +245,87 @@ struct Step {
       st += (h >> l) * (w >> l);
     }
     m.B = d->B; m.N = d->N; m.k = k; m.P = P;
-    m.offlog = offlog; m.ld_offlog = ncol; m.logit_col = 32 * P;
+    m.offlog = offlog.f; m.ld_offlog = ncol; m.logit_col = 32 * P;
     m.ref = ref; m.net_w = (float)d->net_w; m.net_h = (float)d->net_h;
-    m.out = samp;
+    m.out = samp.f; m.out_s = samp.s; m.out_plane = samp.plane;
     if (msda_sample(m, s)) return -1;
     // 2*q + output_proj(.)  (msdeformattn.py:185 adds the identity, transformer.py:321 adds the query again)
-    if (linear(samp, LBM_C, W(wb + LBM_W_MSDA_OUTW), W(wb + LBM_W_MSDA_OUTB), la, LBM_C, Q, LBM_C, LBM_C, ACT_NONE, x, k, 2.f,
-               W(wb + LBM_W_MSDA_LN1G), W(wb + LBM_W_MSDA_LN1B)))
-      return -1;
-    if (linear(la, LBM_C, W(wb + LBM_W_MSDA_F1W), W(wb + LBM_W_MSDA_F1B), hid, 1024, Q, 1024, LBM_C, ACT_GELU)) return -1;
-    return linear(hid, 1024, W(wb + LBM_W_MSDA_F2W), W(wb + LBM_W_MSDA_F2B), out, LBM_C, Q, LBM_C, 1024, ACT_NONE, la, 1, 1.f,
-                  W(wb + LBM_W_MSDA_LN2G), W(wb + LBM_W_MSDA_LN2B));
+    if (linear(samp, LBM_C, wb + LBM_W_MSDA_OUTW, wb + LBM_W_MSDA_OUTB, pre, LBM_C, Q, LBM_C, LBM_C, ACT_NONE, x.f, k, 2.f)) return -1;
+    if (ln(pre.f, wb + LBM_W_MSDA_LN1G, wb + LBM_W_MSDA_LN1B, la, Q)) return -1;
+    if (linear(la, LBM_C, wb + LBM_W_MSDA_F1W, wb + LBM_W_MSDA_F1B, hid, 1024, Q, 1024, LBM_C, ACT_GELU)) return -1;
+    if (linear(hid, 1024, wb + LBM_W_MSDA_F2W, wb + LBM_W_MSDA_F2B, pre, LBM_C, Q, LBM_C, 1024, ACT_NONE, la.f, 1, 1.f)) return -1;
+    return ln(pre.f, wb + LBM_W_MSDA_LN2G, wb + LBM_W_MSDA_LN2B, out, Q);
   }
 
   int run() {
     const int R = (int)lay.R;
     const int hb = d->n_layers * LBM_W_LAYER_COUNT;
+    const long long RC = (long long)R * LBM_C;
     // ---- per-frame, point-independent work ----
-    float* value = buf<float>("value");
+    TV value; value.f = buf<float>("value");
     const int nv = lay.n_vmaps * LBM_C;
-    if (linear(d->tokens, LBM_C, W(hb + LBM_W_HEAD_VPROJ_W), W(hb + LBM_W_HEAD_VPROJ_B), value, nv, (int)(d->B * lay.L), nv, LBM_C))
-      return -1;
+    const long long BL = (long long)d->B * lay.L;
+    TV tok; tok.f = const_cast<float*>(d->tokens);
+    if (split) {
+      tok.s = buf<char>("tok_s"); tok.plane = BL * LBM_C;
+      if (split_planes(d->tokens, tok.s, (char*)tok.s + 2 * tok.plane, BL * LBM_C, s)) return -1;
+    }
+    if (linear(tok, LBM_C, hb + LBM_W_HEAD_VPROJ_W, hb + LBM_W_HEAD_VPROJ_B, value, nv, (int)BL, nv, LBM_C)) return -1;
     float* F = buf<float>("corr_maps");
-    if (corr_maps(d->tokens, buf<float>("inv_norm"), F, d->corr_mix, d->n_layers, d->B, h, w, s)) return -1;
+    if (corr_maps(d->tokens, buf<float>("inv_norm"), F, d->corr_mix, d->n_layers, d->B, h, w, split, s)) return -1;
     if (R == 0) return 0;
 
-    float* x0 = buf<float>("x0");
-    float* x1 = buf<float>("x1");
-    float* ta = buf<float>("ta");
-    float* tb = buf<float>("tb");
-    float* qn = buf<float>("qn");
+    TV xq; xq.f = const_cast<float*>(d->query);
+    if (split) {
+      xq.s = buf<char>("q_s"); xq.plane = RC;
+      if (split_planes(d->query, xq.s, (char*)xq.s + 2 * RC, RC, s)) return -1;
+    }
+    TV x0 = tv("x0", "x0_s", RC), x1 = tv("x1", "x1_s", RC), ta = tv("ta", "ta_s", RC), tb = tv("tb", "tb_s", RC);
+    TV qn = split ? TV{nullptr, buf<char>("qn"), RC} : TV{buf<float>("qn"), nullptr, 0};
     float* corr = buf<float>("corr");
     int* idx = buf<int>("idx");
     float* ref = buf<float>("ref");
-    float* lb = buf<float>("lb");
-    const float* x = d->query;
+    TV lb; lb.f = buf<float>("lb");
+    TV x = xq;
     for (int i = 0; i < d->n_layers; ++i) {
       const int lw = i * LBM_W_LAYER_COUNT;
       const int k = d->topk[i];
       // collision then streaming read-out of the two memories (transformer.py:257-302)
       if (attn_block(lw + LBM_W_LAYER_COLL, x, ta, d->coll_mem, (long long)d->M * LBM_C, d->M, d->ring_head, true, nullptr)) return -1;
-      if (attn_block(lw + LBM_W_LAYER_STREAM, ta, tb, d->stream_mem, (long long)d->M * LBM_C, d->M, d->ring_head, true, qn)) return -1;
+      if (attn_block(lw + LBM_W_LAYER_STREAM, ta, tb, d->stream_mem, (long long)d->M * LBM_C, d->M, d->ring_head, true, &qn)) return -1;
       // correlation + top-k (transformer.py:306-308)
-      GemmArgs g;
-      g.X = qn; g.ldx = LBM_C; g.sX = (long long)d->N * LBM_C;
-      g.W = F + (long long)i * d->B * lay.P0 * LBM_C; g.ldw = LBM_C; g.sW = lay.P0 * LBM_C;
       float* cdst = d->corr[i] ? d->corr[i] : corr;
-      g.Y = cdst; g.ldy = (int)lay.P0; g.sY = (long long)d->N * lay.P0;
-      g.M = d->N; g.N = (int)lay.P0; g.K = LBM_C; g.batch = d->B;
-      if (gemm(g, s)) return -1;
+      if (!split) {
+        GemmArgs g;
+        g.X = qn.f; g.ldx = LBM_C; g.sX = (long long)d->N * LBM_C;
+        g.W = F + (long long)i * d->B * lay.P0 * LBM_C; g.ldw = LBM_C; g.sW = lay.P0 * LBM_C;
+        g.Y = cdst; g.ldy = (int)lay.P0; g.sY = (long long)d->N * lay.P0;
+        g.M = d->N; g.N = (int)lay.P0; g.K = LBM_C; g.batch = d->B;
+        if (gemm(g, s)) return -1;
+      } else {
+        // F holds, per layer, the hi planes of all streams followed by their lo planes
+        const long long plane = (long long)d->B * lay.P0 * LBM_C;
+        GemmSSArgs g;
+        g.A = qn.s; g.a_plane = qn.plane; g.lda = LBM_C; g.sA = (long long)d->N * LBM_C;
+        g.B = (const char*)F + (long long)i * plane * 4; g.b_plane = plane; g.ldb = LBM_C; g.sB = lay.P0 * LBM_C;
+        g.Y = cdst; g.ldy = (int)lay.P0; g.sY = (long long)d->N * lay.P0;
+        g.M = d->N; g.N = (int)lay.P0; g.K = LBM_C; g.batch = d->B;
+        if (gemm_ss(g, s)) return -1;
+      }
       int* idst = d->topk_idx[i] ? d->topk_idx[i] : idx;
       float* rdst = d->ref_points[i] ? d->ref_points[i] : ref;
       if (topk_rows(cdst, lay.P0, (int)lay.P0, k, R, w, d->stride, idst, rdst, nullptr, s)) return -1;
       // lattice deformable attention on the k regions (transformer.py:316-327)
       if (msda_block(lw + LBM_W_LAYER_LATTICE, i, d->n_points, tb, rdst, k, lb)) return -1;
-      if (d->ref_rho[i]) {
-        if (linear(lb, LBM_C, W(lw + LBM_W_LAYER_RHO_W), W(lw + LBM_W_LAYER_RHO_B), d->ref_rho[i], 1, R * k, 1, LBM_C)) return -1;
+      if (d->ref_rho[i]) {   // [1,256] read-out, kept on the exact fp32 path in both modes (weights stay fp32)
+        GemmArgs g;
+        g.X = lb.f; g.ldx = LBM_C; g.W = W(lw + LBM_W_LAYER_RHO_W); g.ldw = LBM_C; g.bias = W(lw + LBM_W_LAYER_RHO_B);
+        g.Y = d->ref_rho[i]; g.ldy = 1; g.M = R * k; g.N = 1; g.K = LBM_C;
+        if (gemm(g, s)) return -1;
       }
       // lattice update (transformer.py:330-338)
-      float* xn = (i & 1) ? x1 : x0;
-      if (attn_block(lw + LBM_W_LAYER_UPDATE, tb, xn, lb, (long long)k * LBM_C, k, 0, false, nullptr)) return -1;
+      const TV& xn = (i & 1) ? x1 : x0;
+      if (attn_block(lw + LBM_W_LAYER_UPDATE, tb, xn, lb.f, (long long)k * LBM_C, k, 0, false, nullptr)) return -1;
       x = xn;
       if (i == d->n_layers - 1 && rdst != ref) {
         if (hipMemcpyAsync(ref, rdst, (size_t)R * 2 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) {
@@ -262,18 +335,18 @@ struct Step {
       }
     }
     // ---- heads (transformer.py:103-149) ----
-    float* hidR = buf<float>("hid");
+    TV hidR; hidR.f = buf<float>("hidR");
     float* pred = buf<float>("pred");
-    float* coll_tok = buf<float>("coll_tok");
+    TV coll_tok; coll_tok.f = buf<float>("coll_tok");
     if (msda_block(hb + LBM_W_HEAD_OFFSET, d->n_layers, d->n_points, x, ref, 1, ta)) return -1;
-    if (linear(ta, LBM_C, W(hb + LBM_W_HEAD_OFFH_W0), W(hb + LBM_W_HEAD_OFFH_B0), hidR, LBM_C, R, LBM_C, LBM_C, ACT_GELU)) return -1;
-    if (offset_final(hidR, W(hb + LBM_W_HEAD_OFFH_W3), W(hb + LBM_W_HEAD_OFFH_B3), ref, (float)d->stride, d->offset, pred, R, s)) return -1;
+    if (linear(ta, LBM_C, hb + LBM_W_HEAD_OFFH_W0, hb + LBM_W_HEAD_OFFH_B0, hidR, LBM_C, R, LBM_C, LBM_C, ACT_GELU)) return -1;
+    if (offset_final(hidR.f, W(hb + LBM_W_HEAD_OFFH_W3), W(hb + LBM_W_HEAD_OFFH_B3), ref, (float)d->stride, d->offset, pred, R, s)) return -1;
     if (msda_block(hb + LBM_W_HEAD_CMEM, d->n_layers + 1, d->n_points_cmem, x, pred, 1, coll_tok)) return -1;
     if (msda_block(hb + LBM_W_HEAD_VIS, d->n_layers + 2, d->n_points, x, ref, 1, ta)) return -1;
-    if (linear(ta, LBM_C, W(hb + LBM_W_HEAD_VISH_W0), W(hb + LBM_W_HEAD_VISH_B0), hidR, LBM_C, R, LBM_C, LBM_C, ACT_GELU)) return -1;
+    if (linear(ta, LBM_C, hb + LBM_W_HEAD_VISH_W0, hb + LBM_W_HEAD_VISH_B0, hidR, LBM_C, R, LBM_C, LBM_C, ACT_GELU)) return -1;
     StateFinalArgs f;
-    f.vis_hidden = hidR; f.w3 = W(hb + LBM_W_HEAD_VISH_W3); f.b3 = W(hb + LBM_W_HEAD_VISH_B3);
-    f.stream_tok = x; f.coll_tok = coll_tok; f.query_init = d->query; f.queried = d->queried;
+    f.vis_hidden = hidR.f; f.w3 = W(hb + LBM_W_HEAD_VISH_W3); f.b3 = W(hb + LBM_W_HEAD_VISH_B3);
+    f.stream_tok = x.f; f.coll_tok = coll_tok.f; f.query_init = d->query; f.queried = d->queried;
     f.stream_out = d->stream_out; f.coll_out = d->coll_out;
     if (d->update_state) {
       f.stream_mem = d->stream_mem; f.coll_mem = d->coll_mem; f.vis_mask = d->vis_mask; f.mem_mask = d->mem_mask;
@@ -298,7 +371,7 @@ const char* lbm_hip_last_error(void) { return g_err; }
 int lbm_hip_linear(const lbm_hip_linear_desc* d, lbm_stream_t stream) {
   LBM_REQUIRE(d != nullptr, "linear: null descriptor");
   if (d->M == 0) return 0;
-  LBM_REQUIRE(d->X && d->W && d->Y, "linear: null argument");
+  LBM_REQUIRE(d->X && (d->W || (d->W_hi && d->W_lo)) && d->Y, "linear: null argument");
   GemmArgs a;
   a.X = d->X; a.W = d->W; a.bias = d->bias; a.Y = d->Y; a.res = d->res;
   a.M = d->M; a.N = d->N; a.K = d->K; a.ldx = d->ldx; a.ldw = d->ldw; a.ldy = d->ldy; a.ldres = d->ldres;
@@ -307,7 +380,26 @@ int lbm_hip_linear(const lbm_hip_linear_desc* d, lbm_stream_t stream) {
   a.res_scale = d->res_scale; a.act = d->act; a.batch = d->batch > 0 ? d->batch : 1;
   a.sX = d->sX; a.sW = d->sW; a.sB = d->sB; a.sY = d->sY; a.sR = d->sR;
   a.ln_gamma = d->ln_gamma; a.ln_beta = d->ln_beta; a.keep = d->keep; a.fallback = d->fallback; a.Yn = d->Yn;
+  if (d->W_hi && d->W_lo) {
+    a.Wh = d->W_hi; a.Wl = d->W_lo;
+    return gemm16(a, (hipStream_t)stream);
+  }
   return gemm(a, (hipStream_t)stream);
+}
+
+int lbm_hip_linear_ss(const lbm_hip_linear_ss_desc* d, lbm_stream_t stream) {
+  LBM_REQUIRE(d != nullptr, "linear_ss: null descriptor");
+  GemmSSArgs a;
+  a.A = d->A; a.B = d->B; a.a_plane = d->a_plane; a.b_plane = d->b_plane; a.bias = d->bias; a.Y = d->Y; a.Ys = d->Ys;
+  a.ys_plane = d->ys_plane; a.res = d->res; a.M = d->M; a.N = d->N; a.K = d->K; a.lda = d->lda; a.ldb = d->ldb; a.ldy = d->ldy;
+  a.ldys = d->ldys; a.ldres = d->ldres; a.res_div = d->res_div > 0 ? d->res_div : 1;
+  a.res_mod = d->res_mod > 0 ? d->res_mod : 0x7fffffff; a.res_scale = d->res_scale; a.act = d->act;
+  a.batch = d->batch > 0 ? d->batch : 1; a.sA = d->sA; a.sB = d->sB; a.sBias = d->sBias; a.sY = d->sY; a.sYs = d->sYs; a.sR = d->sR;
+  return gemm_ss(a, (hipStream_t)stream);
+}
+
+int lbm_hip_split_planes(const float* x, void* hi, void* lo, int64_t n, lbm_stream_t stream) {
+  return split_planes(x, hi, lo, n, (hipStream_t)stream);
 }
 
 int lbm_hip_layernorm(const float* X, const float* gamma, const float* beta, float* Y, int32_t rows, const uint8_t* keep,
@@ -334,7 +426,7 @@ int lbm_hip_pyramid(float* tokens, int32_t B, int32_t h, int32_t w, lbm_stream_t
 
 int lbm_hip_corr_maps(const float* tokens, float* inv_norm, float* F, const float* corr_mix_host, int32_t n_layers, int32_t B,
                       int32_t h, int32_t w, lbm_stream_t stream) {
-  return corr_maps(tokens, inv_norm, F, corr_mix_host, n_layers, B, h, w, (hipStream_t)stream);
+  return corr_maps(tokens, inv_norm, F, corr_mix_host, n_layers, B, h, w, false, (hipStream_t)stream);
 }
 
 int lbm_hip_topk(const float* corr, int64_t ld, int32_t P, int32_t k, int32_t rows, int32_t grid_w, int32_t stride_px,
@@ -370,19 +462,28 @@ int lbm_hip_sample_queries(const float* tokens, int64_t tok_bstride, int32_t ld,
   return sample_queries(tokens, tok_bstride, ld, pts, out, B, N, h, w, net_h, net_w, (hipStream_t)stream);
 }
 
-int lbm_hip_conv2d_nhwc(const float* X, const float* W, const float* bias, const float* res, float* Y, const void* reserved,
+int lbm_hip_conv2d_nhwc(const float* X, const void* W, const float* bias, const float* res, float* Y, const void* W_lo,
                         int32_t B, int32_t H, int32_t Wd, int32_t Cin, int32_t Cout, int32_t kh, int32_t kw, int32_t stride,
                         int32_t pad, int32_t relu, int32_t ldw, lbm_stream_t stream) {
-  (void)reserved;
   ConvArgs c;
-  c.X = X; c.W = W; c.bias = bias; c.res = res; c.Y = Y;
+  c.X = X; c.bias = bias; c.res = res; c.Y = Y;
+  if (W_lo) { c.Wh = W; c.Wl = W_lo; } else { c.W = (const float*)W; }
   c.B = B; c.H = H; c.Wd = Wd; c.Cin = Cin; c.Cout = Cout; c.kh = kh; c.kw = kw; c.stride = stride; c.pad = pad; c.relu = relu;
   c.ldw = ldw > 0 ? ldw : (kh * kw * Cin + 31) / 32 * 32;
-  return conv2d_nhwc(c, (hipStream_t)stream);
+  return W_lo ? conv2d_nhwc16(c, (hipStream_t)stream) : conv2d_nhwc(c, (hipStream_t)stream);
 }
 
 int lbm_hip_maxpool3x3s2_nhwc(const float* x, float* y, int32_t B, int32_t H, int32_t W, int32_t C, lbm_stream_t stream) {
   return maxpool3x3s2_nhwc(x, y, B, H, W, C, (hipStream_t)stream);
+}
+
+int lbm_hip_debug_set(int32_t key, int32_t value) {
+  if (key == 1) {
+    gemm16_force_tile(value);
+    return 0;
+  }
+  set_error("debug_set: unknown key %d", key);
+  return -1;
 }
 
 int lbm_hip_profile_begin(void) {
@@ -455,6 +556,8 @@ int lbm_hip_track_step(const lbm_hip_step_desc* d, lbm_stream_t stream) {
     LBM_REQUIRE(d->query && d->stream_mem && d->coll_mem && d->vis_mask && d->mem_mask, "step: null state pointer");
     LBM_REQUIRE(d->vis && d->rho && d->offset, "step: vis/rho/offset outputs are required");
   }
+  st.split = d->precision == 1;
+  if (st.split) LBM_REQUIRE(d->weights_lo != nullptr, "step: precision 1 needs the lo planes of the weight matrices (weights_lo)");
   st.d = d;
   st.s = (hipStream_t)stream;
   st.ws = (char*)d->workspace;

@@ -75,15 +75,19 @@ __global__ __launch_bounds__(256) void attn_readout_kernel(AttnArgs a) {
     }
   }
   const float inv = l > 0.f ? 1.0f / l : 0.f;
-  float* op = a.out + ((long long)row * LBM_HEADS + g) * LBM_C + c * 4;
+  const long long oo = ((long long)row * LBM_HEADS + g) * LBM_C + c * 4;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) st4(op + i * 64, make_float4(acc[i].x * inv, acc[i].y * inv, acc[i].z * inv, acc[i].w * inv));
+  for (int i = 0; i < 4; ++i) {
+    const float4 v = make_float4(acc[i].x * inv, acc[i].y * inv, acc[i].z * inv, acc[i].w * inv);
+    if (a.out) st4(a.out + oo + i * 64, v);
+    if (a.out_s) st4_split(a.out_s, a.out_plane, oo + i * 64, v);
+  }
   if (a.valid && lane == 0) a.valid[row] = l > 0.f ? 1 : 0;
 }
 
 int attn_readout(const AttnArgs& a, hipStream_t stream) {
   if (a.R == 0) return 0;
-  LBM_REQUIRE(a.U && a.seq && a.out, "attn_readout: null argument");
+  LBM_REQUIRE(a.U && a.seq && (a.out || a.out_s), "attn_readout: null argument");
   LBM_REQUIRE(a.S >= 1 && a.S <= 4096, "attn_readout: sequence length %d out of range", a.S);
   LBM_REQUIRE(a.ring_head >= 0 && a.ring_head < a.S, "attn_readout: ring head %d outside [0,%d)", a.ring_head, a.S);
   LBM_REQUIRE(a.slot_stride % 4 == 0 && a.point_stride % 4 == 0, "attn_readout: strides must be multiples of 4 floats");

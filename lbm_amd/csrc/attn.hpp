@@ -15,6 +15,8 @@ struct AttnArgs {
   const uint8_t* mask_a = nullptr; // [R, S] physical order, non-zero = ignore (vis_mask); may be null
   const uint8_t* mask_b = nullptr; // [R, S] (mem_mask); may be null
   float* out = nullptr;            // [R, 4, 256]  softmax-weighted sums of the raw sequence rows, per head
+  void* out_s = nullptr;           // the same as split f16 planes (hi at out_s, lo out_plane elements further); either may be null
+  long long out_plane = 0;
   uint8_t* valid = nullptr;        // [R] 1 if at least one position was attended; may be null
   int R = 0;
 };

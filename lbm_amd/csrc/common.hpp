@@ -11,6 +11,8 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
 namespace lbm {
 
@@ -73,6 +75,28 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ float gelu_erf(float x) {
   // exact GELU, as nn.GELU() default (transformer.py:348, backbone.py:36)
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+// ---- split representation of an fp32 value for the f16 matrix cores: x = hi + lo * 2^-11 (see gemm16.hip) ----
+__device__ __forceinline__ void split1(float x, _Float16& hi, _Float16& lo) {
+  const float c = __builtin_amdgcn_fmed3f(x, -65000.f, 65000.f);
+  hi = (_Float16)c;
+  lo = (_Float16)((c - (float)hi) * 2048.f);
+}
+__device__ __forceinline__ void split4(const float4 v, half4& hi, half4& lo) {
+  _Float16 h, l;
+  split1(v.x, h, l); hi[0] = h; lo[0] = l;
+  split1(v.y, h, l); hi[1] = h; lo[1] = l;
+  split1(v.z, h, l); hi[2] = h; lo[2] = l;
+  split1(v.w, h, l); hi[3] = h; lo[3] = l;
+}
+// store 4 consecutive values into both planes (8-byte aligned destinations)
+__device__ __forceinline__ void st4_split(void* hi_plane, long long plane, long long off, const float4 v) {
+  half4 h, l;
+  split4(v, h, l);
+  _Float16* p = reinterpret_cast<_Float16*>(hi_plane) + off;
+  *reinterpret_cast<half4*>(p) = h;
+  *reinterpret_cast<half4*>(p + plane) = l;
 }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }

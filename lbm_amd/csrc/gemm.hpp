@@ -9,6 +9,9 @@ enum Act { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU_POST = 2 };  // RELU_POST: relu(
 struct GemmArgs {
   const float* X = nullptr;   // [M, K] row-major, leading dim ldx
   const float* W = nullptr;   // [N, K] row-major (nn.Linear layout), leading dim ldw
+  // split-precision path (gemm16): W pre-split into two f16 planes [N, ldw] (hi, lo * 2^11); W above is ignored
+  const void* Wh = nullptr;
+  const void* Wl = nullptr;
   const float* bias = nullptr;  // [N] or null
   float* Y = nullptr;         // [M, N], leading dim ldy
   const float* res = nullptr;   // optional residual, row index (m / res_div) % res_mod, leading dim ldres
@@ -34,12 +37,39 @@ int gemm(const GemmArgs& a, hipStream_t stream);
 struct ConvArgs {
   const float* X = nullptr;     // [B, H, Wd, Cin], Cin a power of two >= 4
   const float* W = nullptr;     // [Cout, ldw], row = (ky, kx, ci) tap-major, zero-padded to a multiple of 32 columns
+  const void* Wh = nullptr;     // split-precision path: the same matrix as two f16 planes
+  const void* Wl = nullptr;
   const float* bias = nullptr;  // [Cout] (folded BatchNorm shift) or null
   const float* res = nullptr;   // optional [B, Ho, Wo, Cout] residual added before the ReLU
   float* Y = nullptr;           // [B, Ho, Wo, Cout]
   int B = 0, H = 0, Wd = 0, Cin = 0, Cout = 0, kh = 0, kw = 0, stride = 1, pad = 0, relu = 0, ldw = 0;
 };
 int conv2d_nhwc(const ConvArgs& c, hipStream_t stream);
+// split-precision variants (gemm16.hip): fp32-grade results from three f16 MFMAs per product block
+int gemm16(const GemmArgs& a, hipStream_t stream);
+int conv2d_nhwc16(const ConvArgs& c, hipStream_t stream);
+int split_planes(const float* x, void* hi, void* lo, long long n, hipStream_t stream);
+void gemm16_force_tile(int t);
+
+// Both operands pre-split into f16 planes: Y = act(A · Bᵀ + bias) + res_scale · RES, fp32 and/or split output.
+struct GemmSSArgs {
+  const void* A = nullptr;      // f16 hi plane [M, lda]; lo plane a_plane elements further
+  const void* B = nullptr;      // f16 hi plane [N, ldb]; lo plane b_plane elements further
+  long long a_plane = 0, b_plane = 0;
+  const float* bias = nullptr;
+  float* Y = nullptr;           // optional fp32 output [M, ldy]
+  void* Ys = nullptr;           // optional split output (hi plane [M, ldys], lo plane ys_plane elements further)
+  long long ys_plane = 0;
+  const float* res = nullptr;
+  int M = 0, N = 0, K = 0;
+  int lda = 0, ldb = 0, ldy = 0, ldys = 0, ldres = 0;
+  int res_div = 1, res_mod = 0x7fffffff;
+  float res_scale = 1.0f;
+  int act = ACT_NONE;
+  int batch = 1;
+  long long sA = 0, sB = 0, sBias = 0, sY = 0, sYs = 0, sR = 0;
+};
+int gemm_ss(const GemmSSArgs& a, hipStream_t stream);
 int maxpool3x3s2_nhwc(const float* x, float* y, int B, int H, int W, int C, hipStream_t stream);
 
 }  // namespace lbm

@@ -1,0 +1,621 @@
+// fp32-grade GEMM / implicit-GEMM convolution on the gfx950 *f16* matrix cores ("split" precision).
+//
+//   Y[m, n] = act( sum_k X[m, k] * W[n, k] + bias[n] ) + res_scale * RES[(m / res_div) % res_mod, n]
+//
+// gfx950 has no TF32-like fast path for fp32 operands (the fp32 MFMA runs at 1/16 of the f16 rate), so every
+// fp32 operand is represented as an unevaluated sum of two halves,
+//     x  =  hi + lo * 2^-11,      hi = f16(x),   lo = f16((x - hi) * 2^11)           (22-23 significant bits),
+// and the product is assembled from three f16 MFMAs with fp32 accumulation:
+//     X·Wᵀ  ≈  Xh·Whᵀ  +  2^-11 (Xh·Wlᵀ + Xl·Whᵀ)                  (the dropped Xl·Wl term is 2^-22 relative).
+// Products of two f16 values are exact in fp32, so the only error beyond plain fp32 accumulation is the 2^-23
+// representation error of the operands.  Rate: 3 x v_mfma_f32_32x32x16_f16 per 32x32x16 block = 5.3x the
+// algorithmic FLOP/s of v_mfma_f32_32x32x2_f32.  The lo halves are kept scaled by 2^11 so they stay in the f16
+// normal range; magnitudes are clamped to +-65000 (f16 max 65504) before splitting.
+//
+// Operands: W (weights, or the per-frame correlation maps) arrives PRE-SPLIT as two f16 planes [N, ldw] (built
+// once per model by lbm_amd/engine.py, or by the producing kernel); X stays fp32 in HBM and is split by the
+// loader on its way into LDS — that VALU work rides in the issue slots the MFMAs leave free.  Same loader
+// variants, tilings and epilogue as gemm.hip.
+#include "gemm.hpp"
+#include "rows.hpp"
+
+#include <string>
+
+namespace lbm {
+
+
+struct Gemm16Dev {
+  const float* X;
+  const _Float16* Wh;
+  const _Float16* Wl;
+  const float* bias;
+  float* Y;
+  const float* res;
+  int M, N, K;
+  int ldx, ldw, ldy, ldres;
+  int res_div, res_mod;
+  float res_scale;
+  int act;
+  long long sX, sW, sB, sY, sR;
+  int cH, cW, cin_log2, ckh, ckw, cstride, cpad, cHo, cWo;
+};
+
+template <int BM, int BN, int WM, int WN, int WK, int BK, bool CONV>
+__global__ __launch_bounds__(WM* WN* WK * 64) void gemm_s16_kernel(Gemm16Dev a) {
+  constexpr int NT = WM * WN * WK * 64;
+  constexpr int LSB = BK * 2 + 16;           // LDS row stride in bytes (an odd number of 16-byte slots)
+  static_assert((LSB / 16) % 2 == 1, "row stride must be an odd number of 16-byte slots");
+  constexpr int TM = BM / WM / 32;
+  constexpr int TN = BN / WN / 32;
+  constexpr int KW = BK / WK;                // k extent one wave consumes per chunk
+  static_assert(KW % 16 == 0, "each wave consumes k in groups of 16");
+  constexpr int A_P = BM * BK / 4;           // float4 pieces of the fp32 A chunk
+  constexpr int B_P = BN * BK / 8;           // 16-byte pieces of ONE f16 plane of the B chunk
+  static_assert(A_P % NT == 0 && B_P % NT == 0, "staging must divide evenly over the threads");
+  constexpr int A_PER_T = A_P / NT;
+  constexpr int B_PER_T = B_P / NT;
+  constexpr int STAGE = 2 * (BM + BN) * LSB;  // bytes: A hi, A lo, B hi, B lo
+  constexpr int RED = (WK > 1) ? (WK - 1) * BM * BN * 4 : 0;
+  constexpr int LDS_BYTES = (2 * STAGE > RED) ? 2 * STAGE : RED;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wk = wave / (WM * WN);
+  const int wm = (wave / WN) % WM;
+  const int wn = wave % WN;
+  const int r = lane & 31;
+  const int h = lane >> 5;
+
+  const int z = blockIdx.z;
+  const float* __restrict__ X = a.X + z * a.sX;
+  const _Float16* __restrict__ Wh = a.Wh + z * a.sW;
+  const _Float16* __restrict__ Wl = a.Wl + z * a.sW;
+  const int m0 = blockIdx.y * BM;
+  const int n0 = blockIdx.x * BN;
+
+  float4 ra[A_PER_T];
+  uint4 rbh[B_PER_T], rbl[B_PER_T];
+
+  long long a_base[A_PER_T];
+  int a_iy0[A_PER_T], a_ix0[A_PER_T];
+  bool a_ok[A_PER_T];
+#pragma unroll
+  for (int i = 0; i < A_PER_T; ++i) {
+    const int f = tid + i * NT;
+    const int m = m0 + f / (BK / 4);
+    a_ok[i] = m < a.M;
+    if (CONV) {
+      const int hw = a.cHo * a.cWo;
+      const int b = m / hw, rem = m - b * hw;
+      const int oy = rem / a.cWo, ox = rem - oy * a.cWo;
+      a_base[i] = (long long)b * a.cH * a.cW;
+      a_iy0[i] = oy * a.cstride - a.cpad;
+      a_ix0[i] = ox * a.cstride - a.cpad;
+    } else {
+      a_base[i] = (long long)m * a.ldx;
+      a_iy0[i] = a_ix0[i] = 0;
+    }
+  }
+
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < A_PER_T; ++i) {
+      const int f = tid + i * NT;
+      const int k = k0 + (f % (BK / 4)) * 4;
+      ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (CONV) {
+        const int tap = k >> a.cin_log2, ci = k & ((1 << a.cin_log2) - 1);
+        const int ky = tap / a.ckw, kx = tap - ky * a.ckw;
+        const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
+        if (a_ok[i] && ky < a.ckh && iy >= 0 && iy < a.cH && ix >= 0 && ix < a.cW)
+          ra[i] = ld4(X + ((a_base[i] + (long long)iy * a.cW + ix) << a.cin_log2) + ci);
+      } else {
+        if (a_ok[i]) ra[i] = ld4(X + a_base[i] + k);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER_T; ++i) {
+      const int f = tid + i * NT;
+      const int row = f / (BK / 8), c8 = f % (BK / 8);
+      rbh[i] = make_uint4(0u, 0u, 0u, 0u);
+      rbl[i] = make_uint4(0u, 0u, 0u, 0u);
+      if (n0 + row < a.N) {
+        const long long o = (long long)(n0 + row) * a.ldw + k0 + c8 * 8;
+        rbh[i] = *reinterpret_cast<const uint4*>(Wh + o);
+        rbl[i] = *reinterpret_cast<const uint4*>(Wl + o);
+      }
+    }
+  };
+  auto lstore = [&](int buf) {
+    unsigned char* Ah = lds + buf * STAGE;
+    unsigned char* Al = Ah + BM * LSB;
+    unsigned char* Bh = Al + BM * LSB;
+    unsigned char* Bl = Bh + BN * LSB;
+#pragma unroll
+    for (int i = 0; i < A_PER_T; ++i) {
+      const int f = tid + i * NT;
+      const int o = (f / (BK / 4)) * LSB + (f % (BK / 4)) * 8;
+      half4 hi, lo;
+      split4(ra[i], hi, lo);
+      *reinterpret_cast<half4*>(Ah + o) = hi;
+      *reinterpret_cast<half4*>(Al + o) = lo;
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER_T; ++i) {
+      const int f = tid + i * NT;
+      const int o = (f / (BK / 8)) * LSB + (f % (BK / 8)) * 16;
+      *reinterpret_cast<uint4*>(Bh + o) = rbh[i];
+      *reinterpret_cast<uint4*>(Bl + o) = rbl[i];
+    }
+  };
+
+  f32x16 acc[TM][TN], acx[TM][TN];   // hi·hi and the 2^11-scaled cross terms
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        acc[i][j][e] = 0.f;
+        acx[i][j][e] = 0.f;
+      }
+
+  const int nk = a.K / BK;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) gload((kt + 1) * BK);
+    const unsigned char* Ah = lds + cur * STAGE;
+    const unsigned char* Al = Ah + BM * LSB;
+    const unsigned char* Bh = Al + BM * LSB;
+    const unsigned char* Bl = Bh + BN * LSB;
+#pragma unroll
+    for (int s = 0; s < KW / 16; ++s) {
+      // lane (r, h) supplies A[r][k = 8h + j], B[k = 8h + j][r], j = 0..7, of this 16-deep step
+      const int kb = (wk * KW + s * 16 + 8 * h) * 2;
+      half8 fah[TM], fal[TM], fbh[TN], fbl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int o = ((wm * TM + i) * 32 + r) * LSB + kb;
+        fah[i] = *reinterpret_cast<const half8*>(Ah + o);
+        fal[i] = *reinterpret_cast<const half8*>(Al + o);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int o = ((wn * TN + j) * 32 + r) * LSB + kb;
+        fbh[j] = *reinterpret_cast<const half8*>(Bh + o);
+        fbl[j] = *reinterpret_cast<const half8*>(Bl + o);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[i], fbh[j], acc[i][j], 0, 0, 0);
+          acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[i], fbl[j], acx[i][j], 0, 0, 0);
+          acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[i], fbh[j], acx[i][j], 0, 0, 0);
+        }
+    }
+    if (kt + 1 < nk) lstore(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] += acx[i][j][e] * (1.0f / 2048.0f);
+
+  if constexpr (WK > 1) {
+    float* red = reinterpret_cast<float*>(lds);
+    if (wk > 0) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            red[(((wk - 1) * WM * WN + wm * WN + wn) * TM * TN + i * TN + j) * 1024 + e * 64 + lane] = acc[i][j][e];
+    }
+    __syncthreads();
+    if (wk > 0) return;
+#pragma unroll
+    for (int q = 0; q < WK - 1; ++q)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            acc[i][j][e] += red[((q * WM * WN + wm * WN + wn) * TM * TN + i * TN + j) * 1024 + e * 64 + lane];
+  }
+
+  // epilogue: C/D map of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+  float* Y = a.Y + z * a.sY;
+  const float* __restrict__ bias = a.bias ? a.bias + z * a.sB : nullptr;
+  const float* res = a.res ? a.res + z * a.sR : nullptr;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + (wn * TN + j) * 32 + r;
+    if (col >= a.N) continue;
+    const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int rbase = m0 + (wm * TM + i) * 32 + 4 * h;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = rbase + (e & 3) + 8 * (e >> 2);
+        if (row < a.M) {
+          float v = acc[i][j][e] + bv;
+          if (a.act == ACT_GELU) v = gelu_erf(v);
+          if (res) {
+            int rr = row;
+            if (a.res_div != 1) rr /= a.res_div;
+            if (a.res_mod != 0x7fffffff) rr %= a.res_mod;
+            v += a.res_scale * res[(long long)rr * a.ldres + col];
+          }
+          if (a.act == ACT_RELU_POST) v = fmaxf(v, 0.f);
+          Y[(long long)row * a.ldy + col] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN, int WK, int BK, bool CONV>
+static int launch16(const Gemm16Dev& d, int batch, hipStream_t stream) {
+  dim3 grid((d.N + BN - 1) / BN, (d.M + BM - 1) / BM, batch);
+  static const std::string name = std::string(CONV ? "conv_s16<" : "gemm_s16<") + std::to_string(BM) + "," + std::to_string(BN) + "," +
+                                  std::to_string(WM) + "," + std::to_string(WN) + "," + std::to_string(WK) + "," + std::to_string(BK) + ">";
+  const double mnk = (double)d.M * d.N * d.K * batch;
+  const double in_elems = CONV ? (double)d.M / (d.cHo * d.cWo) * d.cH * d.cW * (1 << d.cin_log2) : (double)d.M * d.K * batch;
+  ProfScope prof(name.c_str(), stream, 2.0 * mnk,
+                 4.0 * (in_elems + (double)d.N * d.K * (d.sW || batch == 1 ? batch : 1) + (double)d.M * d.N * batch * (d.res ? 2 : 1)));
+  hipLaunchKernelGGL((gemm_s16_kernel<BM, BN, WM, WN, WK, BK, CONV>), grid, dim3(WM * WN * WK * 64), 0, stream, d);
+  return check_launch(CONV ? "conv_s16" : "gemm_s16");
+}
+
+static int g_force_tile16 = 0;
+void gemm16_force_tile(int t) { g_force_tile16 = t; }
+
+template <bool CONV>
+static int dispatch16(const Gemm16Dev& d, int batch, hipStream_t stream) {
+  const long long big = (long long)((d.M + 127) / 128) * ((d.N + 127) / 128) * batch;
+  const long long mid = (long long)((d.M + 63) / 64) * ((d.N + 63) / 64) * batch;
+  int t = g_force_tile16;
+  if (t == 0) t = (big >= 192 && d.N > 64) ? 1 : (mid >= 192 ? 2 : 3);
+  if (t == 3 && d.K % 64 != 0) t = 2;
+  if (t == 1) return launch16<128, 128, 2, 2, 1, 32, CONV>(d, batch, stream);
+  if (t == 2) return launch16<64, 64, 2, 2, 1, 32, CONV>(d, batch, stream);
+  return launch16<32, 32, 1, 1, 4, 64, CONV>(d, batch, stream);
+}
+
+int gemm16(const GemmArgs& a, hipStream_t stream) {
+  LBM_REQUIRE(a.M >= 0 && a.N > 0 && a.K > 0, "gemm16: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
+  if (a.M == 0) return 0;
+  LBM_REQUIRE(a.Wh && a.Wl, "gemm16: the W operand must be pre-split into f16 planes");
+  LBM_REQUIRE(a.K % 32 == 0, "gemm16: K=%d must be a multiple of 32", a.K);
+  LBM_REQUIRE(a.ldx % 4 == 0 && a.ldw % 8 == 0, "gemm16: ldx=%d must be a multiple of 4, ldw=%d of 8", a.ldx, a.ldw);
+  LBM_REQUIRE(a.ldx >= a.K && a.ldw >= a.K && a.ldy >= a.N, "gemm16: leading dims too small");
+  LBM_REQUIRE(((uintptr_t)a.X & 15) == 0 && ((uintptr_t)a.Wh & 15) == 0 && ((uintptr_t)a.Wl & 15) == 0,
+              "gemm16: X/Wh/Wl must be 16-byte aligned");
+  LBM_REQUIRE(a.sX % 4 == 0 && a.sW % 8 == 0, "gemm16: batch strides must keep 16-byte alignment");
+  LBM_REQUIRE(a.res == nullptr || (a.res_div >= 1 && a.res_mod >= 1 && a.ldres >= a.N), "gemm16: bad residual spec");
+  LBM_REQUIRE(a.batch >= 1 && a.batch <= 65535, "gemm16: batch=%d out of range", a.batch);
+  const bool ln = a.ln_gamma != nullptr;
+  if (ln) LBM_REQUIRE(a.N == LBM_C && a.batch == 1 && a.ldy == LBM_C, "gemm16: fused LayerNorm needs N == 256, ldy == 256");
+
+  Gemm16Dev d{};
+  d.X = a.X; d.Wh = (const _Float16*)a.Wh; d.Wl = (const _Float16*)a.Wl; d.bias = a.bias; d.Y = a.Y; d.res = a.res;
+  d.M = a.M; d.N = a.N; d.K = a.K; d.ldx = a.ldx; d.ldw = a.ldw; d.ldy = a.ldy; d.ldres = a.ldres;
+  d.res_div = a.res_div; d.res_mod = a.res_mod; d.res_scale = a.res_scale; d.act = a.act;
+  d.sX = a.sX; d.sW = a.sW; d.sB = a.sB; d.sY = a.sY; d.sR = a.sR;
+  if (dispatch16<false>(d, a.batch, stream)) return -1;
+  if (ln) return layernorm_rows(a.Y, a.ln_gamma, a.ln_beta, a.Y, a.M, a.keep, a.fallback, a.Yn, stream);
+  return 0;
+}
+
+int conv2d_nhwc16(const ConvArgs& c, hipStream_t stream) {
+  LBM_REQUIRE(c.X && c.Wh && c.Wl && c.Y, "conv2d16: null argument (weights must be pre-split)");
+  LBM_REQUIRE(c.B >= 1 && c.H >= 1 && c.Wd >= 1 && c.Cout >= 1, "conv2d16: bad shape");
+  int lg = 0;
+  while ((1 << lg) < c.Cin) ++lg;
+  LBM_REQUIRE((1 << lg) == c.Cin && c.Cin >= 4, "conv2d16: Cin=%d must be a power of two >= 4", c.Cin);
+  LBM_REQUIRE(c.kh >= 1 && c.kw >= 1 && c.stride >= 1 && c.pad >= 0, "conv2d16: bad kernel spec");
+  const int Ho = (c.H + 2 * c.pad - c.kh) / c.stride + 1, Wo = (c.Wd + 2 * c.pad - c.kw) / c.stride + 1;
+  LBM_REQUIRE(Ho >= 1 && Wo >= 1, "conv2d16: empty output");
+  const int Kt = c.kh * c.kw * c.Cin;
+  const int Kp = (Kt + 31) / 32 * 32;
+  LBM_REQUIRE(c.ldw >= Kp && c.ldw % 8 == 0, "conv2d16: packed weight rows need %d (zero-padded) columns, have %d", Kp, c.ldw);
+  LBM_REQUIRE(((uintptr_t)c.X & 15) == 0 && ((uintptr_t)c.Wh & 15) == 0 && ((uintptr_t)c.Wl & 15) == 0, "conv2d16: operands must be 16-byte aligned");
+  LBM_REQUIRE((long long)c.B * Ho * Wo < 0x7fffffffLL, "conv2d16: too many output pixels");
+  Gemm16Dev d{};
+  d.X = c.X; d.Wh = (const _Float16*)c.Wh; d.Wl = (const _Float16*)c.Wl; d.bias = c.bias; d.Y = c.Y; d.res = c.res;
+  d.M = c.B * Ho * Wo; d.N = c.Cout; d.K = Kp; d.ldx = 0; d.ldw = c.ldw; d.ldy = c.Cout; d.ldres = c.Cout;
+  d.res_div = 1; d.res_mod = 0x7fffffff; d.res_scale = 1.f; d.act = c.relu ? ACT_RELU_POST : ACT_NONE;
+  d.cH = c.H; d.cW = c.Wd; d.cin_log2 = lg; d.ckh = c.kh; d.ckw = c.kw; d.cstride = c.stride; d.cpad = c.pad; d.cHo = Ho; d.cWo = Wo;
+  return dispatch16<true>(d, 1, stream);
+}
+
+// fp32 [rows, cols] -> two f16 planes (hi, lo * 2^11); used for weights at pack time and for per-frame operands
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, _Float16* __restrict__ hi,
+                                                           _Float16* __restrict__ lo, long long n4) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    half4 h, l;
+    split4(ld4(x + i * 4), h, l);
+    *reinterpret_cast<half4*>(hi + i * 4) = h;
+    *reinterpret_cast<half4*>(lo + i * 4) = l;
+  }
+}
+
+int split_planes(const float* x, void* hi, void* lo, long long n, hipStream_t stream) {
+  if (n == 0) return 0;
+  LBM_REQUIRE(x && hi && lo && n % 4 == 0, "split_planes: bad arguments (n must be a multiple of 4)");
+  long long blocks = (n / 4 + 255) / 256;
+  if (blocks > 65535) blocks = 65535;
+  ProfScope prof("split_planes", stream, 0.0, 8.0 * n);
+  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, (_Float16*)hi, (_Float16*)lo, n / 4);
+  return check_launch("split_planes");
+}
+
+// =================================================================================================================
+// gemm_ss: BOTH operands pre-split (f16 hi / lo planes, K-contiguous) and staged global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4: no VGPRs, no VALU), so the whole loop body is ds_read_b128 + MFMA.
+//
+// LDS image of one operand plane: [rows][32 f16] = 64-byte rows, linear in the order the DMA writes them (one
+// wave-instruction = 16 rows x 64 B = 1 KiB).  Bank conflicts are removed by an XOR swizzle applied on the
+// SOURCE side of the DMA and again on the fragment read: the 16-byte chunk c of row r lives in slot
+// c ^ ((r >> 2) & 3).  A ds_read_b128 lane group covers 16 rows with distinct residues mod 16, so its 16 slots
+// (4 (r & 3) + (c ^ ((r >> 2) & 3))) are all different: conflict-free.
+// Pipeline: STAGES LDS buffers; the DMA of chunk kt + STAGES - 1 is in flight while chunk kt is multiplied;
+// each wave retires its own DMAs with a counted s_waitcnt vmcnt(N) and a raw s_barrier publishes them
+// (cdna_hip_programming.md §5 "Pipelining across barriers").
+// =================================================================================================================
+struct GemmSSDev {
+  const _Float16* A;   // hi plane [M, lda]; lo plane at A + a_plane
+  const _Float16* B;   // hi plane [N, ldb]; lo plane at B + b_plane
+  long long a_plane, b_plane;
+  const float* bias;
+  float* Y;            // optional fp32 output [M, ldy]
+  _Float16* Ys;        // optional split output: hi plane [M, ldys], lo plane at Ys + ys_plane
+  long long ys_plane;
+  const float* res;
+  int M, N, K;
+  int lda, ldb, ldy, ldys, ldres;
+  int res_div, res_mod;
+  float res_scale;
+  int act;
+  long long sA, sB, sBias, sY, sYs, sR;   // batch strides (elements)
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else static_assert(N < 0, "unsupported vmcnt");
+}
+
+template <int BM, int BN, int WM, int WN, int STAGES>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_ss_kernel(GemmSSDev a) {
+#if defined(__HIP_DEVICE_COMPILE__)   // LDS-DMA builtins and s_waitcnt asm exist on the device side only
+  constexpr int NW = WM * WN;
+  constexpr int TM = BM / WM / 32;
+  constexpr int TN = BN / WN / 32;
+  constexpr int PLANE_A = BM * 64, PLANE_B = BN * 64;          // bytes of one plane of one stage
+  constexpr int STAGE = 2 * (PLANE_A + PLANE_B);
+  constexpr int PIECES = STAGE / 1024;                         // 1-KiB DMA pieces per stage
+  static_assert(PIECES % NW == 0, "DMA pieces must divide evenly over the waves");
+  constexpr int PPW = PIECES / NW;                             // pieces (= DMA instructions) per wave and stage
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[STAGES * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int r = lane & 31, h = lane >> 5;
+  const int z = blockIdx.z;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+  // ---- DMA source addresses: piece p covers 16 rows of one plane; lane -> (row = lane / 4, slot = lane % 4) ----
+  const _Float16* src[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int p = wave * PPW + i;                              // piece index inside the stage, in LDS order
+    const int pb = p * 1024;
+    const bool isB = pb >= 2 * PLANE_A;
+    const int off = isB ? pb - 2 * PLANE_A : pb;
+    const int plane_bytes = isB ? PLANE_B : PLANE_A;
+    const int lo = off >= plane_bytes ? 1 : 0;
+    const int row = (off - lo * plane_bytes) / 64 + (lane >> 2);
+    const int chunk = (lane & 3) ^ ((row >> 2) & 3);           // which 16-byte source chunk lands in this lane's slot
+    if (isB) {
+      const int n = min(n0 + row, a.N - 1);
+      src[i] = a.B + z * a.sB + lo * a.b_plane + (long long)n * a.ldb + chunk * 8;
+    } else {
+      const int m = min(m0 + row, a.M - 1);
+      src[i] = a.A + z * a.sA + lo * a.a_plane + (long long)m * a.lda + chunk * 8;
+    }
+  }
+  auto issue = [&](int stage, int kt) {
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      unsigned char* dst = lds + stage * STAGE + (wave * PPW + i) * 1024;
+      __builtin_amdgcn_global_load_lds(src[i] + kt * 32, (lds_ptr_t)dst, 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[TM][TN], acx[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        acc[i][j][e] = 0.f;
+        acx[i][j][e] = 0.f;
+      }
+
+  const int nk = a.K / 32;
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (s < nk) issue(s, s);
+
+  // fragment byte offsets inside a plane: row * 64 + ((c ^ ((row >> 2) & 3)) * 16), c = 2 s + h
+  int offA[TM][2], offB[TN][2];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int row = (wm * TM + i) * 32 + r;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) offA[i][s] = row * 64 + (((2 * s + h) ^ ((row >> 2) & 3)) << 4);
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int row = (wn * TN + j) * 32 + r;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) offB[j][s] = row * 64 + (((2 * s + h) ^ ((row >> 2) & 3)) << 4);
+  }
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int pre = kt + STAGES - 1;
+    if (pre < nk) {
+      issue(pre % STAGES, pre);
+      wait_vmcnt<(STAGES - 1) * PPW>();        // everything but the STAGES-1 newest stages has landed
+    } else {
+      wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    const unsigned char* Ah = lds + (kt % STAGES) * STAGE;
+    const unsigned char* Al = Ah + PLANE_A;
+    const unsigned char* Bh = Al + PLANE_A;
+    const unsigned char* Bl = Bh + PLANE_B;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      half8 fah[TM], fal[TM], fbh[TN], fbl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        fah[i] = *reinterpret_cast<const half8*>(Ah + offA[i][s]);
+        fal[i] = *reinterpret_cast<const half8*>(Al + offA[i][s]);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        fbh[j] = *reinterpret_cast<const half8*>(Bh + offB[j][s]);
+        fbl[j] = *reinterpret_cast<const half8*>(Bl + offB[j][s]);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[i], fbh[j], acc[i][j], 0, 0, 0);
+          acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[i], fbl[j], acx[i][j], 0, 0, 0);
+          acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[i], fbh[j], acx[i][j], 0, 0, 0);
+        }
+    }
+    // all waves must be done reading this stage before the next iteration's DMA overwrites it
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+
+  // ---- epilogue ----
+  float* Y = a.Y ? a.Y + z * a.sY : nullptr;
+  _Float16* Yh = a.Ys ? a.Ys + z * a.sYs : nullptr;
+  _Float16* Yl = a.Ys ? Yh + a.ys_plane : nullptr;
+  const float* __restrict__ bias = a.bias ? a.bias + z * a.sBias : nullptr;
+  const float* res = a.res ? a.res + z * a.sR : nullptr;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + (wn * TN + j) * 32 + r;
+    if (col >= a.N) continue;
+    const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int rbase = m0 + (wm * TM + i) * 32 + 4 * h;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = rbase + (e & 3) + 8 * (e >> 2);
+        if (row < a.M) {
+          float v = acc[i][j][e] + acx[i][j][e] * (1.0f / 2048.0f) + bv;
+          if (a.act == ACT_GELU) v = gelu_erf(v);
+          if (res) {
+            int rr = row;
+            if (a.res_div != 1) rr /= a.res_div;
+            if (a.res_mod != 0x7fffffff) rr %= a.res_mod;
+            v += a.res_scale * res[(long long)rr * a.ldres + col];
+          }
+          if (a.act == ACT_RELU_POST) v = fmaxf(v, 0.f);
+          if (Y) Y[(long long)row * a.ldy + col] = v;
+          if (Yh) {
+            const float c = __builtin_amdgcn_fmed3f(v, -65000.f, 65000.f);
+            const _Float16 hh = (_Float16)c;
+            Yh[(long long)row * a.ldys + col] = hh;
+            Yl[(long long)row * a.ldys + col] = (_Float16)((c - (float)hh) * 2048.f);
+          }
+        }
+      }
+    }
+  }
+#endif
+}
+
+template <int BM, int BN, int WM, int WN, int STAGES>
+static int launch_ss(const GemmSSDev& d, int batch, hipStream_t stream) {
+  dim3 grid((d.N + BN - 1) / BN, (d.M + BM - 1) / BM, batch);
+  static const std::string name = std::string("gemm_ss<") + std::to_string(BM) + "," + std::to_string(BN) + "," + std::to_string(WM) +
+                                  "," + std::to_string(WN) + "," + std::to_string(STAGES) + ">";
+  const double mnk = (double)d.M * d.N * d.K * batch;
+  ProfScope prof(name.c_str(), stream, 2.0 * mnk,
+                 4.0 * ((double)d.M * d.K * batch + (double)d.N * d.K * (d.sB || batch == 1 ? batch : 1) +
+                        (double)d.M * d.N * batch * ((d.Y ? 1 : 0) + (d.Ys ? 1 : 0) + (d.res ? 1 : 0))));
+  hipLaunchKernelGGL((gemm_ss_kernel<BM, BN, WM, WN, STAGES>), grid, dim3(WM * WN * 64), 0, stream, d);
+  return check_launch("gemm_ss");
+}
+
+int gemm_ss(const GemmSSArgs& a, hipStream_t stream) {
+  LBM_REQUIRE(a.M >= 0 && a.N > 0 && a.K > 0, "gemm_ss: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
+  if (a.M == 0) return 0;
+  LBM_REQUIRE(a.A && a.B && (a.Y || a.Ys), "gemm_ss: null operand");
+  LBM_REQUIRE(a.K % 32 == 0, "gemm_ss: K=%d must be a multiple of 32", a.K);
+  LBM_REQUIRE(a.lda % 8 == 0 && a.ldb % 8 == 0 && a.lda >= a.K && a.ldb >= a.K, "gemm_ss: lda=%d / ldb=%d must be multiples of 8 and >= K", a.lda, a.ldb);
+  LBM_REQUIRE(a.a_plane % 8 == 0 && a.b_plane % 8 == 0 && a.sA % 8 == 0 && a.sB % 8 == 0, "gemm_ss: plane / batch strides must keep 16-byte alignment");
+  LBM_REQUIRE(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.B & 15) == 0, "gemm_ss: operands must be 16-byte aligned");
+  LBM_REQUIRE(a.Y == nullptr || a.ldy >= a.N, "gemm_ss: ldy too small");
+  LBM_REQUIRE(a.Ys == nullptr || a.ldys >= a.N, "gemm_ss: ldys too small");
+  LBM_REQUIRE(a.res == nullptr || (a.res_div >= 1 && a.res_mod >= 1 && a.ldres >= a.N), "gemm_ss: bad residual spec");
+  LBM_REQUIRE(a.batch >= 1 && a.batch <= 65535, "gemm_ss: batch=%d out of range", a.batch);
+  GemmSSDev d{};
+  d.A = (const _Float16*)a.A; d.B = (const _Float16*)a.B; d.a_plane = a.a_plane; d.b_plane = a.b_plane;
+  d.bias = a.bias; d.Y = a.Y; d.Ys = (_Float16*)a.Ys; d.ys_plane = a.ys_plane; d.res = a.res;
+  d.M = a.M; d.N = a.N; d.K = a.K; d.lda = a.lda; d.ldb = a.ldb; d.ldy = a.ldy; d.ldys = a.ldys; d.ldres = a.ldres;
+  d.res_div = a.res_div; d.res_mod = a.res_mod; d.res_scale = a.res_scale; d.act = a.act;
+  d.sA = a.sA; d.sB = a.sB; d.sBias = a.sBias; d.sY = a.sY; d.sYs = a.sYs; d.sR = a.sR;
+  const long long big = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.batch;
+  int t = g_force_tile16;
+  if (t == 0) t = (big >= 256 && a.N > 64) ? 1 : 2;
+  switch (t) {
+    case 1: return launch_ss<128, 128, 2, 2, 2>(d, a.batch, stream);
+    case 2: return launch_ss<64, 64, 2, 2, 2>(d, a.batch, stream);
+    case 3: return launch_ss<128, 128, 2, 4, 2>(d, a.batch, stream);
+    case 4: return launch_ss<128, 128, 2, 2, 3>(d, a.batch, stream);
+    case 5: return launch_ss<64, 64, 2, 2, 3>(d, a.batch, stream);
+    case 6: return launch_ss<128, 64, 2, 2, 2>(d, a.batch, stream);
+    case 7: return launch_ss<64, 128, 2, 2, 2>(d, a.batch, stream);
+    case 8: return launch_ss<128, 128, 2, 4, 3>(d, a.batch, stream);
+    case 9: return launch_ss<64, 64, 2, 2, 4>(d, a.batch, stream);
+    default: break;
+  }
+  set_error("gemm_ss: unknown tiling %d", t);
+  return -1;
+}
+
+}  // namespace lbm

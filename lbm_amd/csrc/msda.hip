@@ -96,14 +96,18 @@ __global__ __launch_bounds__(256) void msda_sample_kernel(MsdaArgs a) {
     }
     acc.x += __shfl_xor(acc.x, 16); acc.y += __shfl_xor(acc.y, 16); acc.z += __shfl_xor(acc.z, 16); acc.w += __shfl_xor(acc.w, 16);
     acc.x += __shfl_xor(acc.x, 32); acc.y += __shfl_xor(acc.y, 32); acc.z += __shfl_xor(acc.z, 32); acc.w += __shfl_xor(acc.w, 32);
-    if (lane < 16) st4(a.out + (r * a.k + kk) * LBM_C + hd * LBM_HD + cq * 4, acc);
+    if (lane < 16) {
+      const long long oo = (r * a.k + kk) * LBM_C + hd * LBM_HD + cq * 4;
+      if (a.out) st4(a.out + oo, acc);
+      if (a.out_s) st4_split(a.out_s, a.out_plane, oo, acc);
+    }
   }
 }
 
 int msda_sample(const MsdaArgs& a, hipStream_t stream) {
   const long long R = (long long)a.B * a.N;
   if (R == 0) return 0;
-  LBM_REQUIRE(a.value && a.out, "msda_sample: null value/out");
+  LBM_REQUIRE(a.value && (a.out || a.out_s), "msda_sample: null value/out");
   LBM_REQUIRE(a.P >= 1 && a.P <= 16, "msda_sample: P=%d must be in [1,16]", a.P);
   LBM_REQUIRE(a.k >= 1, "msda_sample: k=%d", a.k);
   LBM_REQUIRE(a.ldv % 4 == 0 && a.v_batch_stride % 4 == 0 && ((uintptr_t)a.value & 15) == 0, "msda_sample: value must be 16-byte aligned");

@@ -25,6 +25,8 @@ struct MsdaArgs {
   const float* loc = nullptr;     // [R, 4, 4, P, 2] in [0,1]
   const float* attw = nullptr;    // [R, 4, 4, P]
   float* out = nullptr;           // [R*k, 256]
+  void* out_s = nullptr;          // the same as split f16 planes (lo plane out_plane elements after hi); either may be null
+  long long out_plane = 0;
 };
 
 int msda_sample(const MsdaArgs& a, hipStream_t stream);

@@ -74,6 +74,7 @@ struct CorrMapArgs {
   float* F;             // [n_layers, B, P0, 256]
   float wmix[8][4];     // per layer: corr_conv weights (w0..w3); the +1 residual is added here
   int n_layers, B, h, w, L;
+  int split;            // 1: F is written as split f16 planes, per layer [hi: B*P0*256][lo: B*P0*256]
 };
 
 // bilinear source index/weights of F.interpolate(align_corners=False) from size `in` to `in << lvl`
@@ -131,13 +132,18 @@ __global__ __launch_bounds__(256) void corr_maps_kernel(CorrMapArgs a) {
       o.y = w0 * lv[0].y + w1 * lv[1].y + w2 * lv[2].y + w3 * lv[3].y;
       o.z = w0 * lv[0].z + w1 * lv[1].z + w2 * lv[2].z + w3 * lv[3].z;
       o.w = w0 * lv[0].w + w1 * lv[1].w + w2 * lv[2].w + w3 * lv[3].w;
-      st4(a.F + (((long long)i * a.B + b) * P0 + p) * LBM_C + lane * 4, o);
+      if (a.split) {
+        const long long plane = (long long)a.B * P0 * LBM_C;
+        st4_split(reinterpret_cast<_Float16*>(a.F) + (long long)i * 2 * plane, plane, ((long long)b * P0 + p) * LBM_C + lane * 4, o);
+      } else {
+        st4(a.F + (((long long)i * a.B + b) * P0 + p) * LBM_C + lane * 4, o);
+      }
     }
   }
 }
 
 int corr_maps(const float* tokens, float* inv_norm, float* F, const float* wmix_host, int n_layers, int B, int h, int w,
-              hipStream_t stream) {
+              bool split, hipStream_t stream) {
   LBM_REQUIRE(tokens && inv_norm && F && wmix_host, "corr_maps: null argument");
   LBM_REQUIRE(n_layers >= 1 && n_layers <= 8, "corr_maps: n_layers=%d out of range", n_layers);
   LBM_REQUIRE(B > 0 && h % 8 == 0 && w % 8 == 0, "corr_maps: grid %dx%d must be a multiple of 8", h, w);
@@ -152,7 +158,7 @@ int corr_maps(const float* tokens, float* inv_norm, float* F, const float* wmix_
   }
   if (check_launch("inv_norm")) return -1;
   CorrMapArgs a;
-  a.tok = tokens; a.inv = inv_norm; a.F = F; a.n_layers = n_layers; a.B = B; a.h = h; a.w = w; a.L = L;
+  a.tok = tokens; a.inv = inv_norm; a.F = F; a.n_layers = n_layers; a.B = B; a.h = h; a.w = w; a.L = L; a.split = split ? 1 : 0;
   for (int i = 0; i < 8; ++i)
     for (int l = 0; l < 4; ++l) a.wmix[i][l] = i < n_layers ? wmix_host[i * 4 + l] : 0.f;
   blocks = ((long long)B * P0 + 3) / 4;

@@ -7,8 +7,9 @@ namespace lbm {
 int pyramid_pool(float* tokens, int B, int h, int w, hipStream_t stream);
 
 // inv_norm [B, L] scratch; F [n_layers, B, h*w, 256]; wmix_host = n_layers x 4 corr_conv weights (host memory).
+// split: F is written as the B operand of the split-precision GEMM (per layer: hi planes of all streams, then lo planes)
 int corr_maps(const float* tokens, float* inv_norm, float* F, const float* wmix_host, int n_layers, int B, int h, int w,
-              hipStream_t stream);
+              bool split, hipStream_t stream);
 
 // per row: indices of the k largest values (ties -> lowest index), optional cell centres (x, y) and values.
 int topk_rows(const float* corr, long long ld, int P, int k, int rows, int grid_w, int stride_px, int* idx_out,

@@ -4,9 +4,11 @@
 namespace lbm {
 
 __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* X, const float* __restrict__ gamma,
-                                                             const float* __restrict__ beta, float* Y, int rows,
+                                                             const float* __restrict__ beta, int rows,
                                                              const uint8_t* __restrict__ keep,
-                                                             const float* __restrict__ fallback, float* __restrict__ Yn) {
+                                                             const float* __restrict__ fallback, RowsOut o) {
+  float* Y = o.Y;
+  float* Yn = o.Yn;
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -23,11 +25,14 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* X, con
     const float4 g = ld4(gamma + lane * 4), b = ld4(beta + lane * 4);
     y = make_float4(dx * rstd * g.x + b.x, dy * rstd * g.y + b.y, dz * rstd * g.z + b.z, dw * rstd * g.w + b.w);
   }
-  st4(Y + off, y);
-  if (Yn != nullptr) {
+  if (Y != nullptr) st4(Y + off, y);
+  if (o.Ys != nullptr) st4_split(o.Ys, o.ys_plane, off, y);
+  if (Yn != nullptr || o.Yns != nullptr) {
     const float n = sqrtf(wave_sum(y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w));
     const float inv = 1.0f / fmaxf(n, 1e-12f);
-    st4(Yn + off, make_float4(y.x * inv, y.y * inv, y.z * inv, y.w * inv));
+    const float4 v = make_float4(y.x * inv, y.y * inv, y.z * inv, y.w * inv);
+    if (Yn != nullptr) st4(Yn + off, v);
+    if (o.Yns != nullptr) st4_split(o.Yns, o.yns_plane, off, v);
   }
 }
 
@@ -42,15 +47,23 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restric
   }
 }
 
+int layernorm_rows_ex(const float* X, const float* gamma, const float* beta, int rows, const uint8_t* keep,
+                      const float* fallback, const RowsOut& out, hipStream_t stream) {
+  if (rows == 0) return 0;
+  LBM_REQUIRE(X && gamma && beta && (out.Y || out.Ys) && rows > 0, "layernorm_rows: null argument");
+  LBM_REQUIRE(keep == nullptr || fallback != nullptr, "layernorm_rows: keep mask needs a fallback");
+  const int nout = (out.Y ? 1 : 0) + (out.Ys ? 1 : 0) + (out.Yn ? 1 : 0) + (out.Yns ? 1 : 0);
+  ProfScope prof("layernorm_rows", stream, 0.0, 4.0 * LBM_C * rows * (1.0 + nout));
+  hipLaunchKernelGGL(layernorm_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, X, gamma, beta, rows, keep, fallback, out);
+  return check_launch("layernorm_rows");
+}
+
 int layernorm_rows(const float* X, const float* gamma, const float* beta, float* Y, int rows, const uint8_t* keep,
                    const float* fallback, float* Yn, hipStream_t stream) {
-  if (rows == 0) return 0;
-  LBM_REQUIRE(X && gamma && beta && Y && rows > 0, "layernorm_rows: null argument");
-  LBM_REQUIRE(keep == nullptr || fallback != nullptr, "layernorm_rows: keep mask needs a fallback");
-  ProfScope prof("layernorm_rows", stream, 0.0, 4.0 * LBM_C * rows * (2.0 + (Yn ? 1 : 0)));
-  hipLaunchKernelGGL(layernorm_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, X, gamma, beta, Y, rows, keep,
-                     fallback, Yn);
-  return check_launch("layernorm_rows");
+  RowsOut o;
+  o.Y = Y;
+  o.Yn = Yn;
+  return layernorm_rows_ex(X, gamma, beta, rows, keep, fallback, o, stream);
 }
 
 int l2norm_rows(const float* X, long long ldx, float* Y, long long ldy, long long rows, hipStream_t stream) {

@@ -9,6 +9,18 @@ namespace lbm {
 int layernorm_rows(const float* X, const float* gamma, const float* beta, float* Y, int rows,
                    const uint8_t* keep, const float* fallback, float* Yn, hipStream_t stream);
 
+// Same with any subset of outputs: fp32 Y / Yn and their split-plane twins (operands of the split-precision GEMM).
+struct RowsOut {
+  float* Y = nullptr;
+  void* Ys = nullptr;      // split planes of Y  (hi at Ys, lo ys_plane elements further)
+  long long ys_plane = 0;
+  float* Yn = nullptr;     // L2-normalised rows
+  void* Yns = nullptr;
+  long long yns_plane = 0;
+};
+int layernorm_rows_ex(const float* X, const float* gamma, const float* beta, int rows, const uint8_t* keep,
+                      const float* fallback, const RowsOut& out, hipStream_t stream);
+
 // Y[r] = X[r] / max(|X[r]|_2, 1e-12)   (F.normalize, transformer.py:207)
 int l2norm_rows(const float* X, long long ldx, float* Y, long long ldy, long long rows, hipStream_t stream);
 

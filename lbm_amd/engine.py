@@ -167,7 +167,10 @@ class TrackerWeights:
         n_layers = len(tr.layers)
         n = n_layers * k["LBM_W_LAYER_COUNT"] + k["LBM_W_HEAD_COUNT"]
         self.tensors: List[Optional[torch.Tensor]] = [None] * n
+        self.split: List[Optional[hip.SplitWeight]] = [None] * n      # f16 hi/lo planes of the matrices (precision 1)
         self.memory_size = tr.layers[0].collision_time_emb.shape[1] - 1
+        keep_f32 = {"LBM_W_ATTN_TEMB", "LBM_W_LAYER_RHO_W", "LBM_W_HEAD_OFFH_W3", "LBM_W_HEAD_VISH_W3"}
+        f32_idx = set()
 
         def put(idx, t):
             self.tensors[idx] = t.detach().to(dev, torch.float32).contiguous()
@@ -237,7 +240,21 @@ class TrackerWeights:
             vb.append(att.value_proj.bias)
         put(hb_ + k["LBM_W_HEAD_VPROJ_W"], torch.cat(vw, 0))
         put(hb_ + k["LBM_W_HEAD_VPROJ_B"], torch.cat(vb, 0))
+        # which table entries are matrices of a dense contraction (they get split planes)
+        for i in range(n_layers):
+            base = i * k["LBM_W_LAYER_COUNT"]
+            f32_idx.add(base + k["LBM_W_LAYER_RHO_W"])
+            for blk in ("LBM_W_LAYER_COLL", "LBM_W_LAYER_STREAM", "LBM_W_LAYER_UPDATE"):
+                f32_idx.add(base + k[blk] + k["LBM_W_ATTN_TEMB"])
+        f32_idx.add(hb_ + k["LBM_W_HEAD_OFFH_W3"])
+        f32_idx.add(hb_ + k["LBM_W_HEAD_VISH_W3"])
+        for i, t in enumerate(self.tensors):
+            if t is not None and t.dim() == 2 and i not in f32_idx:
+                self.split[i] = hip.SplitWeight(t)
         self.table = (C.c_void_p * n)(*[None if t is None else t.data_ptr() for t in self.tensors])
+        self.table_hi = (C.c_void_p * n)(*[(None if t is None else t.data_ptr()) if self.split[i] is None else self.split[i].hi
+                                           for i, t in enumerate(self.tensors)])
+        self.table_lo = (C.c_void_p * n)(*[None if sw is None else sw.lo for sw in self.split])
         self.n = n
         self.n_layers = n_layers
         self.device = dev
@@ -246,7 +263,14 @@ class TrackerWeights:
 class TrackEngine:
     """Fills ``lbm_hip_step_desc`` and enqueues one tracking step on the current stream."""
 
-    def __init__(self, cfg: LBMConfig, weights: TrackerWeights):
+    def __init__(self, cfg: LBMConfig, weights: TrackerWeights, precision: Optional[str] = None):
+        """precision: "split" (default; f16 matrix cores with split operands, fp32-grade) or "f32" (exact fp32 MFMA);
+        the environment variable LBM_AMD_PRECISION overrides the default."""
+        import os
+        precision = precision or os.environ.get("LBM_AMD_PRECISION", "split")
+        if precision not in ("split", "f32"):
+            raise ValueError("precision must be 'split' or 'f32'")
+        self.precision = precision
         self.cfg = cfg
         self.w = weights
         self.dev = weights.device
@@ -266,12 +290,18 @@ class TrackEngine:
             d.corr_mix[i] = v
         for i, v in enumerate(self.w.corr_bias):
             d.corr_bias[i] = v
-        d.weights = C.cast(self.w.table, C.POINTER(C.c_void_p))
+        if self.precision == "split":
+            d.precision = 1
+            d.weights = C.cast(self.w.table_hi, C.POINTER(C.c_void_p))
+            d.weights_lo = C.cast(self.w.table_lo, C.POINTER(C.c_void_p))
+        else:
+            d.precision = 0
+            d.weights = C.cast(self.w.table, C.POINTER(C.c_void_p))
         d.n_weights = self.w.n
         return d
 
     def workspace(self, d: hip.StepDesc) -> torch.Tensor:
-        key = (d.B, d.N, d.M)
+        key = (d.B, d.N, d.M, d.precision)
         if self._ws is None or self._ws_key != key:
             nbytes = int(hip.load().lbm_hip_step_workspace_bytes(C.byref(d)))
             if nbytes == 0:

@@ -25,7 +25,7 @@ EXPORTS = (
     "lbm_hip_attn_readout", "lbm_hip_pyramid", "lbm_hip_corr_maps", "lbm_hip_topk", "lbm_hip_msda_sample",
     "lbm_hip_preprocess", "lbm_hip_upcat", "lbm_hip_sample_queries", "lbm_hip_step_workspace_bytes",
     "lbm_hip_track_step", "lbm_hip_step_workspace_offset", "lbm_hip_conv2d_nhwc", "lbm_hip_maxpool3x3s2_nhwc",
-    "lbm_hip_profile_begin", "lbm_hip_profile_end",
+    "lbm_hip_profile_begin", "lbm_hip_profile_end", "lbm_hip_split_planes", "lbm_hip_debug_set", "lbm_hip_linear_ss",
 )
 
 
@@ -40,7 +40,17 @@ class LinearDesc(C.Structure):
                 ("res_scale", C.c_float), ("act", C.c_int32), ("batch", C.c_int32),
                 ("sX", C.c_int64), ("sW", C.c_int64), ("sB", C.c_int64), ("sY", C.c_int64), ("sR", C.c_int64),
                 ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("keep", C.c_void_p), ("fallback", C.c_void_p),
-                ("Yn", C.c_void_p)]
+                ("Yn", C.c_void_p), ("W_hi", C.c_void_p), ("W_lo", C.c_void_p)]
+
+
+class LinearSSDesc(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("a_plane", C.c_int64), ("b_plane", C.c_int64),
+                ("bias", C.c_void_p), ("Y", C.c_void_p), ("Ys", C.c_void_p), ("ys_plane", C.c_int64), ("res", C.c_void_p),
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("lda", C.c_int32), ("ldb", C.c_int32),
+                ("ldy", C.c_int32), ("ldys", C.c_int32), ("ldres", C.c_int32), ("res_div", C.c_int32), ("res_mod", C.c_int32),
+                ("res_scale", C.c_float), ("act", C.c_int32), ("batch", C.c_int32),
+                ("sA", C.c_int64), ("sB", C.c_int64), ("sBias", C.c_int64), ("sY", C.c_int64), ("sYs", C.c_int64),
+                ("sR", C.c_int64)]
 
 
 class MsdaDesc(C.Structure):
@@ -61,6 +71,7 @@ class StepDesc(C.Structure):
                 ("vis_threshold", C.c_float), ("img_h", C.c_float), ("img_w", C.c_float),
                 ("corr_mix", C.c_float * (MAX_LAYERS * 4)), ("corr_bias", C.c_float * MAX_LAYERS),
                 ("weights", C.POINTER(C.c_void_p)), ("n_weights", C.c_int32),
+                ("precision", C.c_int32), ("weights_lo", C.POINTER(C.c_void_p)),
                 ("tokens", C.c_void_p), ("query", C.c_void_p), ("stream_mem", C.c_void_p), ("coll_mem", C.c_void_p),
                 ("vis_mask", C.c_void_p), ("mem_mask", C.c_void_p), ("queried", C.c_void_p),
                 ("coords", C.c_void_p), ("vis", C.c_void_p), ("rho", C.c_void_p), ("offset", C.c_void_p),
@@ -126,6 +137,8 @@ def load() -> C.CDLL:
     lib.lbm_hip_track_step.argtypes = [C.POINTER(StepDesc), C.c_void_p]
     lib.lbm_hip_conv2d_nhwc.argtypes = [C.c_void_p] * 6 + [C.c_int32] * 11 + [C.c_void_p]
     lib.lbm_hip_maxpool3x3s2_nhwc.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p]
+    lib.lbm_hip_linear_ss.argtypes = [C.POINTER(LinearSSDesc), C.c_void_p]
+    lib.lbm_hip_split_planes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.lbm_hip_profile_end.argtypes = [C.POINTER(ProfileEntry), C.c_int32]
     _lib = lib
     return lib
@@ -178,20 +191,65 @@ def profile_end() -> List[dict]:
 # op-level wrappers (used by the module mirrors and by the parity tests)
 # ----------------------------------------------------------------------------------------------
 
-def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = 0,
+class SplitWeight:
+    """A weight matrix [N, K] pre-split into two f16 planes (hi, lo * 2^11) for the split-precision GEMM."""
+
+    def __init__(self, w: torch.Tensor):
+        _require_gpu()
+        w = w.detach().float().contiguous()
+        if w.dim() != 2 or w.shape[1] % 8 != 0:
+            raise HipError("SplitWeight needs a 2-d matrix whose row length is a multiple of 8")
+        self.shape = tuple(w.shape)
+        self.planes = torch.empty(2, *w.shape, device=w.device, dtype=torch.float16)
+        _check(load().lbm_hip_split_planes(w.data_ptr(), self.planes[0].data_ptr(), self.planes[1].data_ptr(), w.numel(),
+                                           _stream()), "lbm_hip_split_planes")
+
+    @property
+    def hi(self) -> int:
+        return self.planes[0].data_ptr()
+
+    @property
+    def lo(self) -> int:
+        return self.planes[1].data_ptr()
+
+
+def linear_ss(a: "SplitWeight", b: "SplitWeight", bias=None, act: int = 0, res=None, res_scale: float = 1.0,
+              want_f32: bool = True, want_split: bool = False):
+    """y = act(a @ b.T + bias) + res_scale * res with both operands pre-split; returns fp32 and/or SplitWeight-like."""
+    _require_gpu()
+    M, K = a.shape
+    N = b.shape[0]
+    d = LinearSSDesc()
+    d.A, d.B, d.a_plane, d.b_plane = a.hi, b.hi, M * K, N * K
+    d.bias, d.res = _p(bias), _p(res)
+    y = torch.empty(M, N, device=a.planes.device, dtype=torch.float32) if want_f32 else None
+    ys = torch.empty(2, M, N, device=a.planes.device, dtype=torch.float16) if want_split else None
+    d.Y, d.Ys, d.ys_plane = _p(y), (ys.data_ptr() if ys is not None else None), M * N
+    d.M, d.N, d.K, d.lda, d.ldb, d.ldy, d.ldys, d.ldres = M, N, K, K, K, N, N, N
+    d.res_div, d.res_mod, d.res_scale, d.act, d.batch = 1, 0, res_scale, act, 1
+    _check(load().lbm_hip_linear_ss(C.byref(d), _stream()), "lbm_hip_linear_ss")
+    return y, ys
+
+
+def linear(x: torch.Tensor, w, bias: Optional[torch.Tensor] = None, act: int = 0,
            res: Optional[torch.Tensor] = None, res_div: int = 1, res_mod: int = 0, res_scale: float = 1.0,
            ln: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, keep: Optional[torch.Tensor] = None,
            fallback: Optional[torch.Tensor] = None, want_normed: bool = False, out: Optional[torch.Tensor] = None):
     """y = act(x @ w.T + bias) + res_scale * res[(m // res_div) % res_mod]  (+ optional LayerNorm)."""
     _require_gpu()
     lib = load()
-    assert x.dim() == 2 and w.dim() == 2 and x.shape[1] == w.shape[1]
+    split = isinstance(w, SplitWeight)
+    assert x.dim() == 2 and len(w.shape) == 2 and x.shape[1] == w.shape[1]
     M, K = x.shape
     N = w.shape[0]
     y = out if out is not None else torch.empty(M, N, device=x.device, dtype=torch.float32)
     yn = torch.empty(M, N, device=x.device, dtype=torch.float32) if want_normed else None
     d = LinearDesc()
-    d.X, d.W, d.bias, d.Y, d.res = _p(x), _p(w), _p(bias), _p(y), _p(res)
+    d.X, d.bias, d.Y, d.res = _p(x), _p(bias), _p(y), _p(res)
+    if split:
+        d.W_hi, d.W_lo = w.hi, w.lo
+    else:
+        d.W = _p(w)
     d.M, d.N, d.K, d.ldx, d.ldw, d.ldy = M, N, K, K, K, N
     d.ldres = res.shape[1] if res is not None else 0
     d.res_div, d.res_mod, d.res_scale = res_div, res_mod, res_scale
@@ -210,7 +268,11 @@ def linear_batched(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bias=Non
     """Raw strided/batched form (element strides sX, sW, sB, sY, sR)."""
     _require_gpu()
     d = LinearDesc()
-    d.X, d.W, d.bias, d.Y, d.res = x.data_ptr(), w.data_ptr(), _p(bias), out.data_ptr(), (res.data_ptr() if res is not None else None)
+    d.X, d.bias, d.Y, d.res = x.data_ptr(), _p(bias), out.data_ptr(), (res.data_ptr() if res is not None else None)
+    if isinstance(w, SplitWeight):
+        d.W_hi, d.W_lo = w.hi, w.lo
+    else:
+        d.W = w.data_ptr()
     d.M, d.N, d.K, d.ldx, d.ldw, d.ldy, d.ldres = M, N, K, ldx, ldw, ldy, ldres
     d.res_div, d.res_mod, d.res_scale, d.act, d.batch = 1, res_mod, 1.0, act, batch
     d.sX, d.sW, d.sB, d.sY, d.sR = strides
@@ -380,7 +442,11 @@ def conv2d_nhwc(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, kh:
     Ho = (H + 2 * pad - kh) // stride + 1
     Wo = (W + 2 * pad - kw) // stride + 1
     y = torch.empty(B, Ho, Wo, Cout, device=x.device, dtype=torch.float32)
-    _check(load().lbm_hip_conv2d_nhwc(_p(x), _p(w_packed), _p(bias), _p(res), _p(y), None, B, H, W, Cin, Cout, kh, kw, stride,
+    if isinstance(w_packed, SplitWeight):
+        w_ptr, w_lo = w_packed.hi, w_packed.lo
+    else:
+        w_ptr, w_lo = _p(w_packed), None
+    _check(load().lbm_hip_conv2d_nhwc(_p(x), w_ptr, _p(bias), _p(res), _p(y), w_lo, B, H, W, Cin, Cout, kh, kw, stride,
                                       pad, 1 if relu else 0, w_packed.shape[1], _stream()), "lbm_hip_conv2d_nhwc")
     return y
 

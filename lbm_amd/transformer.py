@@ -92,6 +92,11 @@ class LBMTransformer(nn.Module):
         self.cfg = LBMConfig(input_size=(H, W), stride=stride, num_layers=n_layer, embed_dim=hidden_dim, num_heads=n_head,
                              num_levels=n_level, num_neighbors=n_neighbor, top_k_regions=n_topk, memory_size=n_mem)
         self._engine: Optional[engine.TrackEngine] = None
+        self.precision: Optional[str] = None   # None -> LBM_AMD_PRECISION or "split"; "f32" = exact fp32 MFMA path
+
+    def set_precision(self, precision: Optional[str]) -> None:
+        self.precision = precision
+        self._engine = None
 
     # -- engine / packed weights ----------------------------------------------------------------
     def invalidate(self) -> None:
@@ -110,7 +115,7 @@ class LBMTransformer(nn.Module):
             if self.random_mask_ratio:
                 raise hip.HipError("random_mask_ratio > 0 is a training-time augmentation; the HIP step implements inference")
             self.cfg.memory_size = self.layers[0].collision_time_emb.shape[1] - 1
-            self._engine = engine.TrackEngine(self.cfg, engine.TrackerWeights(self, self.cfg))
+            self._engine = engine.TrackEngine(self.cfg, engine.TrackerWeights(self, self.cfg), self.precision)
         return self._engine
 
     # -- reference API --------------------------------------------------------------------------

@@ -29,12 +29,16 @@ def _cmp(a, b, **tol):
     np.testing.assert_allclose(a, b, **tol)
 
 
-def _transformer(g, seed=42):
+PRECISIONS = ["f32", "split"]     # exact fp32 MFMA path / f16 matrix cores with split operands (default)
+
+
+def _transformer(g, seed=42, precision=None):
     from lbm_amd.transformer import LBMTransformer
     tr = LBMTransformer(size=list(g.size), stride=g.stride, n_layer=g.num_layers, hidden_dim=g.embed_dim, n_head=g.num_heads,
                         n_level=g.num_levels, n_neighbor=g.num_neighbors, n_mem=g.memory_size, n_topk=g.top_k_regions)
     sd = fx.transformer_state_dict(g, seed)
     tr.load_state_dict(sd, strict=True)
+    tr.set_precision(precision)
     return tr.cuda().eval(), sd
 
 
@@ -54,6 +58,26 @@ def test_linear_against_fp64(hip, M, N, K):
     _cmp(y, want, rtol=1e-5, atol=1e-4)
     y = hip.linear(x, w, b, act=1)
     _cmp(y, torch.nn.functional.gelu(want), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 256, 256), (37, 1024, 256), (300, 256, 1024), (1020, 1536, 256), (4100, 432, 256),
+                                   (513, 130, 64), (9216, 256, 1024)])
+def test_split_precision_linear_matches_fp64_better_than_1e5(hip, M, N, K):
+    """Both split-precision GEMMs (fp32 X split in the loader; both operands pre-split + LDS-DMA) against fp64."""
+    r = np.random.default_rng(M + N)
+    x = torch.from_numpy((r.normal(size=(M, K)) * r.choice([1e-3, 1.0, 30.0], size=(M, 1))).astype(np.float32)).cuda()
+    w = torch.from_numpy((r.normal(size=(N, K)) * 0.1).astype(np.float32)).cuda()
+    b = torch.from_numpy(r.normal(size=(N,)).astype(np.float32)).cuda()
+    res = torch.from_numpy(r.normal(size=(M, N)).astype(np.float32)).cuda()
+    want = torch.nn.functional.gelu(x.double() @ w.double().t() + b.double()) + 2.0 * res.double()
+    scale = (x.double().abs() @ w.double().abs().t()).clamp_min(1.0)
+    ws, xs = hip.SplitWeight(w), hip.SplitWeight(x)
+    y1 = hip.linear(x, ws, b, act=1, res=res, res_scale=2.0)
+    y2, y2s = hip.linear_ss(xs, ws, b, act=1, res=res, res_scale=2.0, want_f32=True, want_split=True)
+    assert float(((y1.double() - want).abs() / scale).max()) < 2e-6
+    assert float(((y2.double() - want).abs() / scale).max()) < 2e-6
+    back = y2s[0].double() + y2s[1].double() / 2048.0            # the split output reconstructs the fp32 one
+    assert float(((back - y2.double()).abs() / y2.double().abs().clamp_min(1e-3)).max()) < 1e-6
 
 
 def test_linear_residual_layernorm_keep(hip):
@@ -194,12 +218,13 @@ def _check_step(out, memory, offset, vis, rho, gold, B, N):
     _cmp(memory["collision"], gold["mem_collision"], **FEAT_TOL)
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("name", ["small256", "full256"])
-def test_transformer_forward_against_reference_golden(hip, golden, name):
+def test_transformer_forward_against_reference_golden(hip, golden, name, precision):
     """LBMTransformer.forward (transformer.py:74-151) on the reference's own outputs."""
     spec, g = fx.GEOMS[name], fx.geometry(name)
     gold = golden("step_" + name)
-    tr, _ = _transformer(g)
+    tr, _ = _transformer(g, precision=precision)
     tr.return_corr = True
     inp = {k: v.cuda() for k, v in fx.step_inputs(g, spec["B"], spec["N"]).items()}
     with torch.no_grad():
@@ -213,10 +238,11 @@ def test_transformer_forward_against_reference_golden(hip, golden, name):
             _cmp(o["corr"][..., ::13], gold[f"corr_s{i}"], rtol=1e-4, atol=5e-5)
 
 
-def test_transformer_forward_against_oracle_full_geometry_many_points(hip):
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_transformer_forward_against_oracle_full_geometry_many_points(hip, precision):
     """N = 300 points (not a multiple of any tile), B = 2, published geometry, oracle on the host."""
     g = fx.geometry("full256")
-    tr, sd = _transformer(g)
+    tr, sd = _transformer(g, precision=precision)
     inp = fx.step_inputs(g, 2, 300, seed=77)
     with torch.no_grad():
         want = ref.transformer_forward(sd, g, inp["query"], inp["feat"], inp["stream"], inp["collision"], inp["vis_mask"],
@@ -249,13 +275,14 @@ def test_empty_point_set_is_a_no_op(hip):
 # sequence level: ring-buffer state against the reference's cat-shifted state
 # ---------------------------------------------------------------------------------------------------------------
 
-def test_sequence_ring_buffer_state_against_reference_golden(hip, golden):
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_sequence_ring_buffer_state_against_reference_golden(hip, golden, precision):
     name = "small256"
     spec, g = fx.GEOMS[name], fx.geometry(name)
     gold = golden("seq_" + name)
     T = gold["coords"].shape[1]
     B, N, M, C = spec["B"], spec["N"], g.memory_size, g.embed_dim
-    tr, _ = _transformer(g)
+    tr, _ = _transformer(g, precision=precision)
     eng = tr.get_engine()
     feats = fx.sequence_feats(g, B, T).cuda()
     q_init = fx.step_inputs(g, B, N, seed=33)["query"].cuda()

@@ -62,6 +62,7 @@ ProfScope::~ProfScope() {
 struct StepLayout {
   long long R, Q, L, P0, kmax;
   int n_vmaps;
+  unsigned long long preq_bytes = 0;
   struct Item {
     const char* name;
     unsigned long long off, bytes;
@@ -125,8 +126,9 @@ static int build_layout(const lbm_hip_step_desc* d, StepLayout& lay) {
   lay.add("lb", (unsigned long long)lay.Q * LBM_C * f);
   lay.add("pred", (unsigned long long)lay.R * 2 * f);
   lay.add("coll_tok", (unsigned long long)lay.R * LBM_C * f);
-  lay.add("pre", (unsigned long long)lay.R * LBM_C * f);
-  lay.add("preq", (unsigned long long)lay.Q * LBM_C * f);
+  // pre-LayerNorm scratch: Q rows, or up to 8 K-split slabs of a small product (only used while 4 * rows/64 * nsplit < 192)
+  lay.preq_bytes = (unsigned long long)(lay.Q > 8 * 3072 ? lay.Q : 8 * 3072) * LBM_C * f;
+  lay.add("preq", lay.preq_bytes);
   lay.add("hidR", (unsigned long long)lay.R * LBM_C * f);
   if (d->precision == 1) {   // split twins (two f16 planes = the same number of bytes as the fp32 tensor)
     lay.add("tok_s", (unsigned long long)d->B * lay.L * LBM_C * f);
@@ -190,15 +192,38 @@ struct Step {
     return gemm_ss(a, s);
   }
 
-  int ln(const float* X, int gi, int bi, const TV& Y, int rows, const uint8_t* keep = nullptr, const float* fallback = nullptr,
-         const TV* Yn = nullptr) {
+  // Y = LayerNorm(X · W[wi]ᵀ + W[bi] + res_scale · res[m / res_div]) (N = 256), rows with keep == 0 replaced by fallback.
+  // The bias / residual / K-split reduction happen in the LayerNorm kernel: with few rows the product is split
+  // along K over gridDim.z (partial slabs in `pre`), which is what keeps all 256 CUs busy at N = 1024 points.
+  int linear_ln(const TV& X, int ldx, int wi, int bi, float* pre, int M, int K, const float* res, int res_div, float res_scale,
+                int gi, int bei, const TV& Y, const uint8_t* keep = nullptr, const float* fallback = nullptr, const TV* Yn = nullptr) {
+    RowsIn in;
+    in.X = pre; in.bias = W(bi); in.res = res; in.res_div = res_div; in.res_scale = res_scale;
+    if (!split) {
+      GemmArgs a;
+      a.X = X.f; a.ldx = ldx; a.W = W(wi); a.ldw = K; a.Y = pre; a.ldy = LBM_C; a.M = M; a.N = LBM_C; a.K = K;
+      if (gemm(a, s)) return -1;
+    } else {
+      int nsplit = 1;
+      const long long tiles = (long long)((M + 63) / 64) * (LBM_C / 64);
+      while (nsplit < 8 && tiles * nsplit < 192 && K / (nsplit * 2) >= 128 && (K / (nsplit * 2)) % 32 == 0) nsplit *= 2;
+      LBM_REQUIRE((unsigned long long)nsplit * M * LBM_C * sizeof(float) <= pre_bytes, "step: K-split slabs exceed the scratch buffer");
+      GemmSSArgs a;
+      a.A = X.s; a.a_plane = X.plane; a.lda = ldx;
+      a.B = d->weights[wi]; a.b_plane = ((const char*)d->weights_lo[wi] - (const char*)d->weights[wi]) / 2; a.ldb = K;
+      a.Y = pre; a.ldy = LBM_C; a.M = M; a.N = LBM_C; a.K = K / nsplit;
+      a.batch = nsplit; a.sA = K / nsplit; a.sB = K / nsplit; a.sY = (long long)M * LBM_C;
+      if (gemm_ss(a, s)) return -1;
+      in.nslab = nsplit; in.slab_stride = (long long)M * LBM_C;
+    }
     RowsOut o;
     o.Y = Y.f; o.Ys = Y.s; o.ys_plane = Y.plane;
     if (Yn) {
       o.Yn = Yn->f; o.Yns = Yn->s; o.yns_plane = Yn->plane;
     }
-    return layernorm_rows_ex(X, W(gi), W(bi), rows, keep, fallback, o, s);
+    return layernorm_rows_in(in, W(gi), W(bei), M, keep, fallback, o, s);
   }
+  unsigned long long pre_bytes = 0;
 
   // memory / lattice-update attention block: x_in [R,256] -> x_out [R,256]
   int attn_block(int wb, const TV& x_in, const TV& x_out, const float* seq, long long point_stride, int S, int ring_head,
@@ -207,7 +232,7 @@ struct Step {
     TV U;   U.f = buf<float>("U");
     TV mbar = split ? TV{nullptr, buf<char>("mbar"), (long long)R * 1024} : TV{buf<float>("mbar"), nullptr, 0};
     TV hid = split ? TV{nullptr, buf<char>("hid"), (long long)R * 1024} : TV{buf<float>("hid"), nullptr, 0};
-    TV pre; pre.f = buf<float>("pre");
+    TV pre; pre.f = buf<float>("preq");
     TV y = tv("tc", "tc_s", (long long)R * LBM_C);
     uint8_t* valid = masked ? buf<uint8_t>("valid") : nullptr;
     if (linear(x_in, LBM_C, wb + LBM_W_ATTN_G, wb + LBM_W_ATTN_GB, U, 1024, R, 1024, LBM_C)) return -1;
@@ -218,11 +243,12 @@ struct Step {
     a.mask_b = masked ? d->mem_mask : nullptr;
     a.out = mbar.f; a.out_s = mbar.s; a.out_plane = mbar.plane; a.valid = valid; a.R = R;
     if (attn_readout(a, s)) return -1;
-    if (linear(mbar, 1024, wb + LBM_W_ATTN_HM, wb + LBM_W_ATTN_HB, pre, LBM_C, R, LBM_C, 1024, ACT_NONE, x_in.f, 1, 1.f)) return -1;
-    if (ln(pre.f, wb + LBM_W_ATTN_LN1G, wb + LBM_W_ATTN_LN1B, y, R)) return -1;
+    if (linear_ln(mbar, 1024, wb + LBM_W_ATTN_HM, wb + LBM_W_ATTN_HB, pre.f, R, 1024, x_in.f, 1, 1.f, wb + LBM_W_ATTN_LN1G,
+                  wb + LBM_W_ATTN_LN1B, y))
+      return -1;
     if (linear(y, LBM_C, wb + LBM_W_ATTN_F1W, wb + LBM_W_ATTN_F1B, hid, 1024, R, 1024, LBM_C, ACT_GELU)) return -1;
-    if (linear(hid, 1024, wb + LBM_W_ATTN_F2W, wb + LBM_W_ATTN_F2B, pre, LBM_C, R, LBM_C, 1024, ACT_NONE, y.f, 1, 1.f)) return -1;
-    return ln(pre.f, wb + LBM_W_ATTN_LN2G, wb + LBM_W_ATTN_LN2B, x_out, R, valid, x_in.f, Yn);
+    return linear_ln(hid, 1024, wb + LBM_W_ATTN_F2W, wb + LBM_W_ATTN_F2B, pre.f, R, 1024, y.f, 1, 1.f, wb + LBM_W_ATTN_LN2G,
+                     wb + LBM_W_ATTN_LN2B, x_out, valid, x_in.f, Yn);
   }
 
   // deformable block: token x [R,256] (replicated k times) sampled at ref [R,k,2] -> out [R*k,256]
@@ -250,11 +276,12 @@ struct Step {
     m.out = samp.f; m.out_s = samp.s; m.out_plane = samp.plane;
     if (msda_sample(m, s)) return -1;
     // 2*q + output_proj(.)  (msdeformattn.py:185 adds the identity, transformer.py:321 adds the query again)
-    if (linear(samp, LBM_C, wb + LBM_W_MSDA_OUTW, wb + LBM_W_MSDA_OUTB, pre, LBM_C, Q, LBM_C, LBM_C, ACT_NONE, x.f, k, 2.f)) return -1;
-    if (ln(pre.f, wb + LBM_W_MSDA_LN1G, wb + LBM_W_MSDA_LN1B, la, Q)) return -1;
+    if (linear_ln(samp, LBM_C, wb + LBM_W_MSDA_OUTW, wb + LBM_W_MSDA_OUTB, pre.f, Q, LBM_C, x.f, k, 2.f, wb + LBM_W_MSDA_LN1G,
+                  wb + LBM_W_MSDA_LN1B, la))
+      return -1;
     if (linear(la, LBM_C, wb + LBM_W_MSDA_F1W, wb + LBM_W_MSDA_F1B, hid, 1024, Q, 1024, LBM_C, ACT_GELU)) return -1;
-    if (linear(hid, 1024, wb + LBM_W_MSDA_F2W, wb + LBM_W_MSDA_F2B, pre, LBM_C, Q, LBM_C, 1024, ACT_NONE, la.f, 1, 1.f)) return -1;
-    return ln(pre.f, wb + LBM_W_MSDA_LN2G, wb + LBM_W_MSDA_LN2B, out, Q);
+    return linear_ln(hid, 1024, wb + LBM_W_MSDA_F2W, wb + LBM_W_MSDA_F2B, pre.f, Q, 1024, la.f, 1, 1.f, wb + LBM_W_MSDA_LN2G,
+                     wb + LBM_W_MSDA_LN2B, out);
   }
 
   int run() {
@@ -482,6 +509,10 @@ int lbm_hip_debug_set(int32_t key, int32_t value) {
     gemm16_force_tile(value);
     return 0;
   }
+  if (key == 2) {
+    gemm16_debug(value);
+    return 0;
+  }
   set_error("debug_set: unknown key %d", key);
   return -1;
 }
@@ -557,6 +588,7 @@ int lbm_hip_track_step(const lbm_hip_step_desc* d, lbm_stream_t stream) {
     LBM_REQUIRE(d->vis && d->rho && d->offset, "step: vis/rho/offset outputs are required");
   }
   st.split = d->precision == 1;
+  st.pre_bytes = st.lay.preq_bytes;
   if (st.split) LBM_REQUIRE(d->weights_lo != nullptr, "step: precision 1 needs the lo planes of the weight matrices (weights_lo)");
   st.d = d;
   st.s = (hipStream_t)stream;

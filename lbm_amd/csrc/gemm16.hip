@@ -281,7 +281,9 @@ static int launch16(const Gemm16Dev& d, int batch, hipStream_t stream) {
 }
 
 static int g_force_tile16 = 0;
+static int g_dbg16 = 0;
 void gemm16_force_tile(int t) { g_force_tile16 = t; }
+void gemm16_debug(int flags) { g_dbg16 = flags; }
 
 template <bool CONV>
 static int dispatch16(const Gemm16Dev& d, int batch, hipStream_t stream) {
@@ -391,6 +393,7 @@ struct GemmSSDev {
   float res_scale;
   int act;
   long long sA, sB, sBias, sY, sYs, sR;   // batch strides (elements)
+  int dbg;   // ablation switches (tuning only): 1 = no DMA after the prologue, 2 = no MFMA, 4 = no output stores
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -398,12 +401,54 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
   else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
   else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
   else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
   else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else if constexpr (N == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
   else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if constexpr (N == 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+  else if constexpr (N == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+  else if constexpr (N == 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
   else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else if constexpr (N == 17) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+  else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+  else if constexpr (N == 19) asm volatile("s_waitcnt vmcnt(19)" ::: "memory");
+  else if constexpr (N == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+  else if constexpr (N == 21) asm volatile("s_waitcnt vmcnt(21)" ::: "memory");
+  else if constexpr (N == 22) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+  else if constexpr (N == 23) asm volatile("s_waitcnt vmcnt(23)" ::: "memory");
+  else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+  else if constexpr (N == 25) asm volatile("s_waitcnt vmcnt(25)" ::: "memory");
+  else if constexpr (N == 26) asm volatile("s_waitcnt vmcnt(26)" ::: "memory");
+  else if constexpr (N == 27) asm volatile("s_waitcnt vmcnt(27)" ::: "memory");
+  else if constexpr (N == 28) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
+  else if constexpr (N == 29) asm volatile("s_waitcnt vmcnt(29)" ::: "memory");
+  else if constexpr (N == 30) asm volatile("s_waitcnt vmcnt(30)" ::: "memory");
+  else if constexpr (N == 31) asm volatile("s_waitcnt vmcnt(31)" ::: "memory");
+  else if constexpr (N == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+  else if constexpr (N == 33) asm volatile("s_waitcnt vmcnt(33)" ::: "memory");
+  else if constexpr (N == 34) asm volatile("s_waitcnt vmcnt(34)" ::: "memory");
+  else if constexpr (N == 35) asm volatile("s_waitcnt vmcnt(35)" ::: "memory");
+  else if constexpr (N == 36) asm volatile("s_waitcnt vmcnt(36)" ::: "memory");
+  else if constexpr (N == 37) asm volatile("s_waitcnt vmcnt(37)" ::: "memory");
+  else if constexpr (N == 38) asm volatile("s_waitcnt vmcnt(38)" ::: "memory");
+  else if constexpr (N == 39) asm volatile("s_waitcnt vmcnt(39)" ::: "memory");
+  else if constexpr (N == 40) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+  else if constexpr (N == 41) asm volatile("s_waitcnt vmcnt(41)" ::: "memory");
+  else if constexpr (N == 42) asm volatile("s_waitcnt vmcnt(42)" ::: "memory");
+  else if constexpr (N == 43) asm volatile("s_waitcnt vmcnt(43)" ::: "memory");
+  else if constexpr (N == 44) asm volatile("s_waitcnt vmcnt(44)" ::: "memory");
+  else if constexpr (N == 45) asm volatile("s_waitcnt vmcnt(45)" ::: "memory");
+  else if constexpr (N == 46) asm volatile("s_waitcnt vmcnt(46)" ::: "memory");
+  else if constexpr (N == 47) asm volatile("s_waitcnt vmcnt(47)" ::: "memory");
+  else if constexpr (N == 48) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
   else static_assert(N < 0, "unsupported vmcnt");
 }
 
@@ -489,7 +534,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_ss_kernel(GemmSSDev a) {
 
   for (int kt = 0; kt < nk; ++kt) {
     const int pre = kt + STAGES - 1;
-    if (pre < nk) {
+    if (pre < nk && !(a.dbg & 1)) {
       issue(pre % STAGES, pre);
       wait_vmcnt<(STAGES - 1) * PPW>();        // everything but the STAGES-1 newest stages has landed
     } else {
@@ -513,14 +558,21 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_ss_kernel(GemmSSDev a) {
         fbh[j] = *reinterpret_cast<const half8*>(Bh + offB[j][s]);
         fbl[j] = *reinterpret_cast<const half8*>(Bl + offB[j][s]);
       }
+      if (a.dbg & 2) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(fah[i]), "v"(fal[i]));
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[i], fbh[j], acc[i][j], 0, 0, 0);
-          acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[i], fbl[j], acx[i][j], 0, 0, 0);
-          acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[i], fbh[j], acx[i][j], 0, 0, 0);
-        }
+        for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(fbh[j]), "v"(fbl[j]));
+      } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[i], fbh[j], acc[i][j], 0, 0, 0);
+            acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[i], fbl[j], acx[i][j], 0, 0, 0);
+            acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[i], fbh[j], acx[i][j], 0, 0, 0);
+          }
+      }
     }
     // all waves must be done reading this stage before the next iteration's DMA overwrites it
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -546,6 +598,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_ss_kernel(GemmSSDev a) {
         const int row = rbase + (e & 3) + 8 * (e >> 2);
         if (row < a.M) {
           float v = acc[i][j][e] + acx[i][j][e] * (1.0f / 2048.0f) + bv;
+          if ((a.dbg & 4) && v != 123456.789f) continue;
           if (a.act == ACT_GELU) v = gelu_erf(v);
           if (res) {
             int rr = row;
@@ -599,9 +652,10 @@ int gemm_ss(const GemmSSArgs& a, hipStream_t stream) {
   d.M = a.M; d.N = a.N; d.K = a.K; d.lda = a.lda; d.ldb = a.ldb; d.ldy = a.ldy; d.ldys = a.ldys; d.ldres = a.ldres;
   d.res_div = a.res_div; d.res_mod = a.res_mod; d.res_scale = a.res_scale; d.act = a.act;
   d.sA = a.sA; d.sB = a.sB; d.sBias = a.sBias; d.sY = a.sY; d.sYs = a.sYs; d.sR = a.sR;
+  d.dbg = g_dbg16;
   const long long big = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.batch;
   int t = g_force_tile16;
-  if (t == 0) t = (big >= 256 && a.N > 64) ? 1 : 2;
+  if (t == 0) t = (big >= 128 && a.N > 64) ? 3 : 2;   // measured: scripts/gemm_bench.py
   switch (t) {
     case 1: return launch_ss<128, 128, 2, 2, 2>(d, a.batch, stream);
     case 2: return launch_ss<64, 64, 2, 2, 2>(d, a.batch, stream);
@@ -612,6 +666,13 @@ int gemm_ss(const GemmSSArgs& a, hipStream_t stream) {
     case 7: return launch_ss<64, 128, 2, 2, 2>(d, a.batch, stream);
     case 8: return launch_ss<128, 128, 2, 4, 3>(d, a.batch, stream);
     case 9: return launch_ss<64, 64, 2, 2, 4>(d, a.batch, stream);
+    case 10: return launch_ss<128, 128, 2, 4, 4>(d, a.batch, stream);
+    case 11: return launch_ss<128, 256, 2, 4, 3>(d, a.batch, stream);
+    case 12: return launch_ss<256, 128, 4, 2, 3>(d, a.batch, stream);
+    case 13: return launch_ss<128, 64, 2, 2, 4>(d, a.batch, stream);
+    case 14: return launch_ss<64, 128, 2, 2, 4>(d, a.batch, stream);
+    case 15: return launch_ss<128, 64, 4, 2, 4>(d, a.batch, stream);
+    case 16: return launch_ss<64, 256, 2, 4, 3>(d, a.batch, stream);
     default: break;
   }
   set_error("gemm_ss: unknown tiling %d", t);

@@ -3,10 +3,11 @@
 
 namespace lbm {
 
-__global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* X, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(RowsIn in, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, int rows,
                                                              const uint8_t* __restrict__ keep,
                                                              const float* __restrict__ fallback, RowsOut o) {
+  const float* X = in.X;
   float* Y = o.Y;
   float* Yn = o.Yn;
   const int lane = threadIdx.x & 63;
@@ -17,7 +18,19 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* X, con
   if (keep != nullptr && keep[row] == 0) {
     y = ld4(fallback + off);
   } else {
-    const float4 x = ld4(X + off);
+    float4 x = ld4(X + off);
+    for (int sl = 1; sl < in.nslab; ++sl) {
+      const float4 p = ld4(X + sl * in.slab_stride + off);
+      x.x += p.x; x.y += p.y; x.z += p.z; x.w += p.w;
+    }
+    if (in.bias != nullptr) {
+      const float4 p = ld4(in.bias + lane * 4);
+      x.x += p.x; x.y += p.y; x.z += p.z; x.w += p.w;
+    }
+    if (in.res != nullptr) {
+      const float4 p = ld4(in.res + (long long)(row / in.res_div) * LBM_C + lane * 4);
+      x.x += in.res_scale * p.x; x.y += in.res_scale * p.y; x.z += in.res_scale * p.z; x.w += in.res_scale * p.w;
+    }
     const float mean = wave_sum(x.x + x.y + x.z + x.w) * (1.0f / LBM_C);
     const float dx = x.x - mean, dy = x.y - mean, dz = x.z - mean, dw = x.w - mean;
     const float var = wave_sum(dx * dx + dy * dy + dz * dz + dw * dw) * (1.0f / LBM_C);
@@ -47,15 +60,23 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restric
   }
 }
 
-int layernorm_rows_ex(const float* X, const float* gamma, const float* beta, int rows, const uint8_t* keep,
+int layernorm_rows_in(const RowsIn& in, const float* gamma, const float* beta, int rows, const uint8_t* keep,
                       const float* fallback, const RowsOut& out, hipStream_t stream) {
   if (rows == 0) return 0;
-  LBM_REQUIRE(X && gamma && beta && (out.Y || out.Ys) && rows > 0, "layernorm_rows: null argument");
+  LBM_REQUIRE(in.X && gamma && beta && (out.Y || out.Ys) && rows > 0, "layernorm_rows: null argument");
+  LBM_REQUIRE(in.nslab >= 1 && in.res_div >= 1, "layernorm_rows: bad input description");
   LBM_REQUIRE(keep == nullptr || fallback != nullptr, "layernorm_rows: keep mask needs a fallback");
   const int nout = (out.Y ? 1 : 0) + (out.Ys ? 1 : 0) + (out.Yn ? 1 : 0) + (out.Yns ? 1 : 0);
-  ProfScope prof("layernorm_rows", stream, 0.0, 4.0 * LBM_C * rows * (1.0 + nout));
-  hipLaunchKernelGGL(layernorm_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, X, gamma, beta, rows, keep, fallback, out);
+  ProfScope prof("layernorm_rows", stream, 0.0, 4.0 * LBM_C * rows * (in.nslab + (in.res ? 1.0 / in.res_div : 0.0) + nout));
+  hipLaunchKernelGGL(layernorm_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, in, gamma, beta, rows, keep, fallback, out);
   return check_launch("layernorm_rows");
+}
+
+int layernorm_rows_ex(const float* X, const float* gamma, const float* beta, int rows, const uint8_t* keep,
+                      const float* fallback, const RowsOut& out, hipStream_t stream) {
+  RowsIn in;
+  in.X = X;
+  return layernorm_rows_in(in, gamma, beta, rows, keep, fallback, out, stream);
 }
 
 int layernorm_rows(const float* X, const float* gamma, const float* beta, float* Y, int rows, const uint8_t* keep,

@@ -21,6 +21,20 @@ struct RowsOut {
 int layernorm_rows_ex(const float* X, const float* gamma, const float* beta, int rows, const uint8_t* keep,
                       const float* fallback, const RowsOut& out, hipStream_t stream);
 
+// LayerNorm whose input is assembled on the fly: x[r] = sum_{s < nslab} X[s * slab_stride + r] + bias + res_scale * res[r / res_div]
+// (the K-split partial products of a GEMM, its bias and its residual: the reduction the GEMM epilogue would do).
+struct RowsIn {
+  const float* X = nullptr;
+  int nslab = 1;
+  long long slab_stride = 0;     // elements
+  const float* bias = nullptr;   // [256] or null
+  const float* res = nullptr;    // [rows / res_div, 256] or null
+  int res_div = 1;
+  float res_scale = 1.f;
+};
+int layernorm_rows_in(const RowsIn& in, const float* gamma, const float* beta, int rows, const uint8_t* keep,
+                      const float* fallback, const RowsOut& out, hipStream_t stream);
+
 // Y[r] = X[r] / max(|X[r]|_2, 1e-12)   (F.normalize, transformer.py:207)
 int l2norm_rows(const float* X, long long ldx, float* Y, long long ldy, long long rows, hipStream_t stream);
 

@@ -13,16 +13,15 @@ TILES = [int(v) for v in os.environ.get("TILES", "1,2,3,4,5,6,7,8,9").split(",")
 
 
 def timeit(fn, n=20):
+    """GPU time per launch in us from the library's per-launch HIP events (no CPU launch gaps)."""
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
+    hip.profile_begin()
     for _ in range(n):
         fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / n * 1e3
+    prof = [p for p in hip.profile_end() if p["name"] != "split_planes"]
+    return sum(p["total_ms"] for p in prof) / n * 1e3
 
 
 def main():

@@ -143,6 +143,23 @@ int lbm_hip_conv2d_nhwc(const float* X, const void* W, const float* bias, const 
 int lbm_hip_maxpool3x3s2_nhwc(const float* x, float* y, int32_t B, int32_t H, int32_t W, int32_t C,
                               lbm_stream_t stream);
 
+/* Split-precision encoder (same reference lines as above).  A "split tensor" is two f16 planes: hi at the pointer,
+ * lo `*_plane` elements further (lbm_hip_split_planes).
+ * conv2d_nhwc_ss: activation X [B,H,W,Cin] (Cin a power of two >= 32) and packed weights both split; im2col rows are
+ *   gathered straight into LDS by DMA, out-of-image taps read `zeros` (>= 16 zero bytes of device memory).  Output as
+ *   fp32 (Y) and/or split (Ys).  `scratch` (optional, fp32) lets small problems split K over more workgroups.
+ * maxpool / upcat / pyramid *_s variants additionally (or only) emit the split twin of their output.             */
+int lbm_hip_conv2d_nhwc_ss(const void* X, int64_t x_plane, const void* W_hi, const void* W_lo, const float* bias,
+                           const float* res, float* Y, void* Ys, int64_t ys_plane, const void* zeros, void* scratch,
+                           uint64_t scratch_bytes, int32_t B, int32_t H, int32_t Wd, int32_t Cin, int32_t Cout, int32_t kh,
+                           int32_t kw, int32_t stride, int32_t pad, int32_t relu, int32_t ldw, lbm_stream_t stream);
+int lbm_hip_maxpool3x3s2_nhwc_s(const float* x, float* y, void* ys, int64_t ys_plane, int32_t B, int32_t H, int32_t W,
+                                int32_t C, lbm_stream_t stream);
+int lbm_hip_upcat_s(const float* p1, const float* p2, const float* p3, float* out, void* outs, int64_t outs_plane, int32_t B,
+                    int32_t h, int32_t w, lbm_stream_t stream);
+int lbm_hip_pyramid_s(float* tokens, void* tokens_s, int64_t tokens_plane, int32_t B, int32_t h, int32_t w,
+                      lbm_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Whole tracking step = LBMTransformer.forward (transformer.py:74-151) + the state roll and output
  * scaling of LBM_online.online_forward (lbm_online.py:143-156), enqueued as one call.
@@ -223,6 +240,8 @@ typedef struct {
   const void* const* weights_lo;
   /* inputs */
   const float* tokens;                  /* [B, L, 256] pyramid (levels filled) */
+  const void* tokens_split;             /* optional (precision 1): split twin of tokens (lbm_hip_pyramid_s), lo plane
+                                           B*L*256 elements after hi; NULL = the step derives it itself */
   const float* query;                   /* [B, N, 256] initial point tokens */
   float* stream_mem;                    /* [B, N, M, 256] ring buffers */
   float* coll_mem;

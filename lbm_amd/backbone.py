@@ -62,6 +62,7 @@ class Backbone(nn.Module):
         self.frame_pos_embedding = nn.Parameter(torch.zeros(1, embed_dim, self.H_prime, self.W_prime))
         nn.init.trunc_normal_(self.frame_pos_embedding, std=0.02)
         self._packed = None          # engine.EncoderWeights, rebuilt when parameters change
+        self.precision = None        # None -> LBM_AMD_PRECISION or "split"; "f32" = exact fp32 MFMA path
 
     # -- weight packing -------------------------------------------------------------------------
     def _apply(self, fn, *a, **k):
@@ -74,8 +75,17 @@ class Backbone(nn.Module):
 
     def packed(self) -> "engine.EncoderWeights":
         if self._packed is None:
-            self._packed = engine.EncoderWeights(self)
+            self._packed = engine.EncoderWeights(self, self.precision)
         return self._packed
+
+    def set_precision(self, precision) -> None:
+        self.precision = precision
+        self._packed = None
+
+    @property
+    def last_tokens_split(self):
+        """Split-plane twin of the token buffer produced by the most recent encode_tokens() (None on the fp32 path)."""
+        return None if self._packed is None else self._packed.tokens_split
 
     # -- reference API --------------------------------------------------------------------------
     def encode_tokens(self, frames: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:

@@ -131,7 +131,7 @@ static int build_layout(const lbm_hip_step_desc* d, StepLayout& lay) {
   lay.add("preq", lay.preq_bytes);
   lay.add("hidR", (unsigned long long)lay.R * LBM_C * f);
   if (d->precision == 1) {   // split twins (two f16 planes = the same number of bytes as the fp32 tensor)
-    lay.add("tok_s", (unsigned long long)d->B * lay.L * LBM_C * f);
+    if (d->tokens_split == nullptr) lay.add("tok_s", (unsigned long long)d->B * lay.L * LBM_C * f);
     lay.add("q_s", (unsigned long long)lay.R * LBM_C * f);
     lay.add("x0_s", (unsigned long long)lay.R * LBM_C * f);
     lay.add("x1_s", (unsigned long long)lay.R * LBM_C * f);
@@ -294,8 +294,13 @@ struct Step {
     const long long BL = (long long)d->B * lay.L;
     TV tok; tok.f = const_cast<float*>(d->tokens);
     if (split) {
-      tok.s = buf<char>("tok_s"); tok.plane = BL * LBM_C;
-      if (split_planes(d->tokens, tok.s, (char*)tok.s + 2 * tok.plane, BL * LBM_C, s)) return -1;
+      tok.plane = BL * LBM_C;
+      if (d->tokens_split) {
+        tok.s = const_cast<void*>(d->tokens_split);
+      } else {
+        tok.s = buf<char>("tok_s");
+        if (split_planes(d->tokens, tok.s, (char*)tok.s + 2 * tok.plane, BL * LBM_C, s)) return -1;
+      }
     }
     if (linear(tok, LBM_C, hb + LBM_W_HEAD_VPROJ_W, hb + LBM_W_HEAD_VPROJ_B, value, nv, (int)BL, nv, LBM_C)) return -1;
     float* F = buf<float>("corr_maps");
@@ -558,6 +563,32 @@ int lbm_hip_profile_end(lbm_hip_profile_entry* out, int32_t cap) {
     ++n;
   }
   return n;
+}
+
+int lbm_hip_conv2d_nhwc_ss(const void* X, int64_t x_plane, const void* W_hi, const void* W_lo, const float* bias, const float* res,
+                           float* Y, void* Ys, int64_t ys_plane, const void* zeros, void* scratch, uint64_t scratch_bytes, int32_t B,
+                           int32_t H, int32_t Wd, int32_t Cin, int32_t Cout, int32_t kh, int32_t kw, int32_t stride, int32_t pad,
+                           int32_t relu, int32_t ldw, lbm_stream_t stream) {
+  ConvSSArgs c;
+  c.X = X; c.x_plane = x_plane; c.Wh = W_hi; c.Wl = W_lo; c.bias = bias; c.res = res; c.Y = Y; c.Ys = Ys; c.ys_plane = ys_plane;
+  c.zeros = zeros; c.scratch = scratch; c.scratch_bytes = scratch_bytes;
+  c.B = B; c.H = H; c.Wd = Wd; c.Cin = Cin; c.Cout = Cout; c.kh = kh; c.kw = kw; c.stride = stride; c.pad = pad; c.relu = relu;
+  c.ldw = ldw > 0 ? ldw : kh * kw * Cin;
+  return conv2d_nhwc_ss(c, (hipStream_t)stream);
+}
+
+int lbm_hip_maxpool3x3s2_nhwc_s(const float* x, float* y, void* ys, int64_t ys_plane, int32_t B, int32_t H, int32_t W, int32_t C,
+                                lbm_stream_t stream) {
+  return maxpool3x3s2_nhwc(x, y, B, H, W, C, (hipStream_t)stream, ys, ys_plane);
+}
+
+int lbm_hip_upcat_s(const float* p1, const float* p2, const float* p3, float* out, void* outs, int64_t outs_plane, int32_t B,
+                    int32_t h, int32_t w, lbm_stream_t stream) {
+  return upcat(p1, p2, p3, out, B, h, w, (hipStream_t)stream, outs, outs_plane);
+}
+
+int lbm_hip_pyramid_s(float* tokens, void* tokens_s, int64_t tokens_plane, int32_t B, int32_t h, int32_t w, lbm_stream_t stream) {
+  return pyramid_pool(tokens, B, h, w, (hipStream_t)stream, tokens_s, tokens_plane);
 }
 
 uint64_t lbm_hip_step_workspace_bytes(const lbm_hip_step_desc* d) {

@@ -54,7 +54,8 @@ int preprocess(const float* frames, long long frame_bstride, float* out, int B, 
 
 // backbone.py:57-62: cat([p1, up2(p2), up4(p3)]) with pixel-major (NHWC) 64-channel maps -> [B*h*w, 192].
 __global__ __launch_bounds__(256) void upcat_kernel(const float* __restrict__ p1, const float* __restrict__ p2,
-                                                    const float* __restrict__ p3, float* __restrict__ out, int B, int h, int w) {
+                                                    const float* __restrict__ p3, float* __restrict__ out, int B, int h, int w,
+                                                    void* outs, long long outs_plane) {
   const long long total = (long long)B * h * w * 48;   // float4 pieces
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const int f = (int)(i % 48);
@@ -81,16 +82,18 @@ __global__ __launch_bounds__(256) void upcat_kernel(const float* __restrict__ p1
       r.z = ly0 * (lx0 * v00.z + lx1 * v01.z) + ly1 * (lx0 * v10.z + lx1 * v11.z);
       r.w = ly0 * (lx0 * v00.w + lx1 * v01.w) + ly1 * (lx0 * v10.w + lx1 * v11.w);
     }
-    st4(out + pix * 192 + f * 4, r);
+    if (out) st4(out + pix * 192 + f * 4, r);
+    if (outs) st4_split(outs, outs_plane, pix * 192 + f * 4, r);
   }
 }
 
-int upcat(const float* p1, const float* p2, const float* p3, float* out, int B, int h, int w, hipStream_t stream) {
-  LBM_REQUIRE(p1 && p2 && p3 && out && B > 0 && h % 4 == 0 && w % 4 == 0, "upcat: bad arguments");
+int upcat(const float* p1, const float* p2, const float* p3, float* out, int B, int h, int w, hipStream_t stream, void* outs,
+          long long outs_plane) {
+  LBM_REQUIRE(p1 && p2 && p3 && (out || outs) && B > 0 && h % 4 == 0 && w % 4 == 0, "upcat: bad arguments");
   long long blocks = ((long long)B * h * w * 48 + 255) / 256;
   if (blocks > 65535) blocks = 65535;
   ProfScope prof("upcat", stream, 0.0, 4.0 * B * h * w * (64.0 + 16.0 + 4.0 + 192.0));
-  hipLaunchKernelGGL(upcat_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p1, p2, p3, out, B, h, w);
+  hipLaunchKernelGGL(upcat_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p1, p2, p3, out, B, h, w, outs, outs_plane);
   return check_launch("upcat");
 }
 

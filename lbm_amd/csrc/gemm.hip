@@ -306,7 +306,7 @@ int conv2d_nhwc(const ConvArgs& c, hipStream_t stream) {
 
 // 3x3 stride-2 pad-1 max pooling on NHWC (torchvision resnet stem, backbone.py:23)
 __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W,
-                                                           int Cq, int Ho, int Wo) {
+                                                           int Cq, int Ho, int Wo, void* ys, long long ys_plane) {
   const long long total = (long long)B * Ho * Wo * Cq;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const int c4 = (int)(i % Cq);
@@ -324,17 +324,18 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float* __restri
           m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
         }
       }
-    st4(y + pix * Cq * 4 + c4 * 4, m);
+    if (y) st4(y + pix * Cq * 4 + c4 * 4, m);
+    if (ys) st4_split(ys, ys_plane, pix * Cq * 4 + c4 * 4, m);
   }
 }
 
-int maxpool3x3s2_nhwc(const float* x, float* y, int B, int H, int W, int C, hipStream_t stream) {
-  LBM_REQUIRE(x && y && B >= 1 && H >= 1 && W >= 1 && C % 4 == 0, "maxpool: bad arguments");
+int maxpool3x3s2_nhwc(const float* x, float* y, int B, int H, int W, int C, hipStream_t stream, void* ys, long long ys_plane) {
+  LBM_REQUIRE(x && (y || ys) && B >= 1 && H >= 1 && W >= 1 && C % 4 == 0, "maxpool: bad arguments");
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   long long blocks = ((long long)B * Ho * Wo * (C / 4) + 255) / 256;
   if (blocks > 65535) blocks = 65535;
   ProfScope prof("maxpool3x3s2", stream, 0.0, 4.0 * B * C * ((double)H * W + (double)Ho * Wo));
-  hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, y, B, H, W, C / 4, Ho, Wo);
+  hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, y, B, H, W, C / 4, Ho, Wo, ys, ys_plane);
   return check_launch("maxpool3x3s2");
 }
 

@@ -71,6 +71,25 @@ struct GemmSSArgs {
   long long sA = 0, sB = 0, sBias = 0, sY = 0, sYs = 0, sR = 0;
 };
 int gemm_ss(const GemmSSArgs& a, hipStream_t stream);
-int maxpool3x3s2_nhwc(const float* x, float* y, int B, int H, int W, int C, hipStream_t stream);
+
+// NHWC convolution with split operands staged by LDS-DMA gather (Cin a power of two >= 32).
+struct ConvSSArgs {
+  const void* X = nullptr;        // activation, f16 hi plane [B, H, Wd, Cin]; lo plane x_plane elements further
+  long long x_plane = 0;
+  const void* Wh = nullptr;       // packed weights [Cout, ldw], columns (ky, kx, ci): hi and lo planes
+  const void* Wl = nullptr;
+  const float* bias = nullptr;
+  const float* res = nullptr;     // optional fp32 residual [B, Ho, Wo, Cout] added before the ReLU
+  float* Y = nullptr;             // optional fp32 output
+  void* Ys = nullptr;             // optional split output (lo plane ys_plane elements further)
+  long long ys_plane = 0;
+  const void* zeros = nullptr;    // >= 16 zero bytes in device memory (what out-of-image taps read)
+  void* scratch = nullptr;        // optional fp32 scratch for K-split slabs
+  unsigned long long scratch_bytes = 0;
+  int B = 0, H = 0, Wd = 0, Cin = 0, Cout = 0, kh = 0, kw = 0, stride = 1, pad = 0, relu = 0, ldw = 0;
+};
+int conv2d_nhwc_ss(const ConvSSArgs& c, hipStream_t stream);
+int maxpool3x3s2_nhwc(const float* x, float* y, int B, int H, int W, int C, hipStream_t stream, void* ys = nullptr,
+                      long long ys_plane = 0);
 
 }  // namespace lbm

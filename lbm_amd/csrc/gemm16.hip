@@ -394,6 +394,11 @@ struct GemmSSDev {
   int act;
   long long sA, sB, sBias, sY, sYs, sR;   // batch strides (elements)
   int dbg;   // ablation switches (tuning only): 1 = no DMA after the prologue, 2 = no MFMA, 4 = no output stores
+  // implicit-GEMM convolution (CONV): A is an NHWC activation as split planes [B, cH, cW, Cin], Cin a multiple of 32;
+  // row m = (b, oy, ox), column k = (ky, kx, ci).  Taps outside the image read `zeros` (>= 16 zero bytes).
+  int cH, cW, cin_log2, ckw, cstride, cpad, cHo, cWo;
+  const void* zeros;
+  int kt0_per_z;   // K-split over gridDim.z for convolutions: block z starts at chunk z * kt0_per_z
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -452,7 +457,7 @@ __device__ __forceinline__ void wait_vmcnt() {
   else static_assert(N < 0, "unsupported vmcnt");
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES>
+template <int BM, int BN, int WM, int WN, int STAGES, bool CONV>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_ss_kernel(GemmSSDev a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // LDS-DMA builtins and s_waitcnt asm exist on the device side only
   constexpr int NW = WM * WN;
@@ -475,8 +480,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_ss_kernel(GemmSSDev a) {
 
   // ---- DMA source addresses: piece p covers 16 rows of one plane; lane -> (row = lane / 4, slot = lane % 4) ----
   const _Float16* src[PPW];
+  int c_iy0[PPW], c_ix0[PPW];      // CONV: top-left input pixel of the A row this lane fetches (or a huge value: no row)
 #pragma unroll
   for (int i = 0; i < PPW; ++i) {
+    c_iy0[i] = c_ix0[i] = 0;
     const int p = wave * PPW + i;                              // piece index inside the stage, in LDS order
     const int pb = p * 1024;
     const bool isB = pb >= 2 * PLANE_A;
@@ -488,16 +495,45 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_ss_kernel(GemmSSDev a) {
     if (isB) {
       const int n = min(n0 + row, a.N - 1);
       src[i] = a.B + z * a.sB + lo * a.b_plane + (long long)n * a.ldb + chunk * 8;
+    } else if (CONV) {
+      const int m = m0 + row;
+      const int hw = a.cHo * a.cWo;
+      const int b = m / hw, rem = m - b * hw;
+      const int oy = rem / a.cWo, ox = rem - oy * a.cWo;
+      c_iy0[i] = m < a.M ? oy * a.cstride - a.cpad : -0x40000000;
+      c_ix0[i] = ox * a.cstride - a.cpad;
+      // pointer to channel (chunk * 8) of input pixel (b, iy0, ix0); may lie outside the tensor until a tap is added
+      src[i] = a.A + lo * a.a_plane + ((((long long)b * a.cH + c_iy0[i]) * a.cW + c_ix0[i]) << a.cin_log2) + chunk * 8;
+      if (m >= a.M) src[i] = a.A;
     } else {
       const int m = min(m0 + row, a.M - 1);
       src[i] = a.A + z * a.sA + lo * a.a_plane + (long long)m * a.lda + chunk * 8;
     }
   }
+  const int ktz = CONV ? z * a.kt0_per_z : 0;
   auto issue = [&](int stage, int kt) {
+    // CONV: the 32 channels of chunk kt belong to one tap (Cin % 32 == 0): (ky, kx, ci0) are block-uniform
+    int ky = 0, kx = 0;
+    long long tap_off = 0;
+    if (CONV) {
+      const int k = (ktz + kt) * 32;
+      const int tap = k >> a.cin_log2, ci0 = k & ((1 << a.cin_log2) - 1);
+      ky = tap / a.ckw;
+      kx = tap - ky * a.ckw;
+      tap_off = (((long long)ky * a.cW + kx) << a.cin_log2) + ci0;
+    }
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
       unsigned char* dst = lds + stage * STAGE + (wave * PPW + i) * 1024;
-      __builtin_amdgcn_global_load_lds(src[i] + kt * 32, (lds_ptr_t)dst, 16, 0, 0);
+      const bool isB = (wave * PPW + i) * 1024 >= 2 * PLANE_A;
+      const _Float16* g;
+      if (CONV && !isB) {
+        const bool ok = (unsigned)(c_iy0[i] + ky) < (unsigned)a.cH && (unsigned)(c_ix0[i] + kx) < (unsigned)a.cW;
+        g = ok ? src[i] + tap_off : reinterpret_cast<const _Float16*>(a.zeros);
+      } else {
+        g = src[i] + (long long)(ktz + kt) * 32;
+      }
+      __builtin_amdgcn_global_load_lds(g, (lds_ptr_t)dst, 16, 0, 0);
     }
   };
 
@@ -621,17 +657,93 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_ss_kernel(GemmSSDev a) {
 #endif
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES>
+template <int BM, int BN, int WM, int WN, int STAGES, bool CONV = false>
 static int launch_ss(const GemmSSDev& d, int batch, hipStream_t stream) {
   dim3 grid((d.N + BN - 1) / BN, (d.M + BM - 1) / BM, batch);
-  static const std::string name = std::string("gemm_ss<") + std::to_string(BM) + "," + std::to_string(BN) + "," + std::to_string(WM) +
+  static const std::string name = std::string(CONV ? "conv_ss<" : "gemm_ss<") + std::to_string(BM) + "," + std::to_string(BN) + "," + std::to_string(WM) +
                                   "," + std::to_string(WN) + "," + std::to_string(STAGES) + ">";
   const double mnk = (double)d.M * d.N * d.K * batch;
   ProfScope prof(name.c_str(), stream, 2.0 * mnk,
                  4.0 * ((double)d.M * d.K * batch + (double)d.N * d.K * (d.sB || batch == 1 ? batch : 1) +
                         (double)d.M * d.N * batch * ((d.Y ? 1 : 0) + (d.Ys ? 1 : 0) + (d.res ? 1 : 0))));
-  hipLaunchKernelGGL((gemm_ss_kernel<BM, BN, WM, WN, STAGES>), grid, dim3(WM * WN * 64), 0, stream, d);
-  return check_launch("gemm_ss");
+  hipLaunchKernelGGL((gemm_ss_kernel<BM, BN, WM, WN, STAGES, CONV>), grid, dim3(WM * WN * 64), 0, stream, d);
+  return check_launch(CONV ? "conv_ss" : "gemm_ss");
+}
+
+// out = relu?(sum of K-split slabs + bias + res) as fp32 and / or split planes (the epilogue of a K-split convolution)
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int nslab, long long slab_stride,
+                                                          const float* __restrict__ bias, const float* __restrict__ res, int N4,
+                                                          long long total4, int relu, float* __restrict__ Y, void* Ys,
+                                                          long long ys_plane) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+    float4 v = ld4(slabs + i * 4);
+    for (int sl = 1; sl < nslab; ++sl) {
+      const float4 p = ld4(slabs + sl * slab_stride + i * 4);
+      v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+    }
+    if (bias) {
+      const float4 p = ld4(bias + (i % N4) * 4);
+      v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+    }
+    if (res) {
+      const float4 p = ld4(res + i * 4);
+      v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+    }
+    if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+    if (Y) st4(Y + i * 4, v);
+    if (Ys) st4_split(Ys, ys_plane, i * 4, v);
+  }
+}
+
+int conv2d_nhwc_ss(const ConvSSArgs& c, hipStream_t stream) {
+  LBM_REQUIRE(c.X && c.Wh && c.Wl && (c.Y || c.Ys) && c.zeros, "conv2d_ss: null argument");
+  LBM_REQUIRE(c.B >= 1 && c.H >= 1 && c.Wd >= 1 && c.Cout >= 1, "conv2d_ss: bad shape");
+  int lg = 0;
+  while ((1 << lg) < c.Cin) ++lg;
+  LBM_REQUIRE((1 << lg) == c.Cin && c.Cin >= 32, "conv2d_ss: Cin=%d must be a power of two >= 32", c.Cin);
+  LBM_REQUIRE(c.kh >= 1 && c.kw >= 1 && c.stride >= 1 && c.pad >= 0, "conv2d_ss: bad kernel spec");
+  const int Ho = (c.H + 2 * c.pad - c.kh) / c.stride + 1, Wo = (c.Wd + 2 * c.pad - c.kw) / c.stride + 1;
+  LBM_REQUIRE(Ho >= 1 && Wo >= 1, "conv2d_ss: empty output");
+  const int K = c.kh * c.kw * c.Cin;
+  LBM_REQUIRE(c.ldw >= K && c.ldw % 8 == 0, "conv2d_ss: packed weight rows need %d columns, have %d", K, c.ldw);
+  LBM_REQUIRE(((uintptr_t)c.X & 15) == 0 && ((uintptr_t)c.Wh & 15) == 0 && ((uintptr_t)c.Wl & 15) == 0 && ((uintptr_t)c.zeros & 15) == 0 &&
+                  c.x_plane % 8 == 0,
+              "conv2d_ss: operands must be 16-byte aligned");
+  const long long M = (long long)c.B * Ho * Wo;
+  LBM_REQUIRE(M < 0x7fffffffLL, "conv2d_ss: too many output pixels");
+  GemmSSDev d{};
+  d.A = (const _Float16*)c.X; d.a_plane = c.x_plane; d.B = (const _Float16*)c.Wh;
+  d.b_plane = ((const char*)c.Wl - (const char*)c.Wh) / 2; d.ldb = c.ldw;
+  d.M = (int)M; d.N = c.Cout; d.K = K; d.ldy = c.Cout; d.ldys = c.Cout; d.ldres = c.Cout;
+  d.res_div = 1; d.res_mod = 0x7fffffff; d.res_scale = 1.f;
+  d.cH = c.H; d.cW = c.Wd; d.cin_log2 = lg; d.ckw = c.kw; d.cstride = c.stride; d.cpad = c.pad; d.cHo = Ho; d.cWo = Wo;
+  d.zeros = c.zeros; d.dbg = g_dbg16;
+  // few output pixels (one stream, deep layers): split K over gridDim.z into fp32 slabs and reduce them afterwards
+  const int nk = K / 32;
+  const long long big = ((M + 127) / 128) * ((c.Cout + 127) / 128);
+  const long long mid = ((M + 63) / 64) * ((c.Cout + 63) / 64);
+  int nsplit = 1;
+  if (c.scratch != nullptr) {
+    while (nsplit < 16 && mid * nsplit < 192 && nk % (nsplit * 2) == 0 && nk / (nsplit * 2) >= 4 &&
+           (unsigned long long)(nsplit * 2) * M * c.Cout * sizeof(float) <= c.scratch_bytes)
+      nsplit *= 2;
+  }
+  int rc;
+  if (nsplit == 1) {
+    d.bias = c.bias; d.res = c.res; d.act = c.relu ? ACT_RELU_POST : ACT_NONE;
+    d.Y = c.Y; d.Ys = (_Float16*)c.Ys; d.ys_plane = c.ys_plane; d.kt0_per_z = 0;
+    rc = (big >= 128 && c.Cout > 64) ? launch_ss<128, 128, 2, 4, 2, true>(d, 1, stream) : launch_ss<64, 64, 2, 2, 2, true>(d, 1, stream);
+    return rc;
+  }
+  d.Y = (float*)c.scratch; d.sY = M * c.Cout; d.K = K / nsplit; d.kt0_per_z = nk / nsplit; d.act = ACT_NONE;
+  if (launch_ss<64, 64, 2, 2, 2, true>(d, nsplit, stream)) return -1;
+  const long long total4 = M * c.Cout / 4;
+  long long blocks = (total4 + 255) / 256;
+  if (blocks > 65535) blocks = 65535;
+  ProfScope prof("slab_reduce", stream, 0.0, 4.0 * M * c.Cout * (nsplit + 2.0));
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)c.scratch, nsplit, M * c.Cout, c.bias,
+                     c.res, c.Cout / 4, total4, c.relu, c.Y, c.Ys, c.ys_plane);
+  return check_launch("slab_reduce");
 }
 
 int gemm_ss(const GemmSSArgs& a, hipStream_t stream) {

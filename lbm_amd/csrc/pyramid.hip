@@ -15,7 +15,18 @@
 namespace lbm {
 
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pyramid_pool_kernel(float* __restrict__ tok, int B, int h, int w, int L) {
+// also used (with `toks`) to emit the split-plane twin of the whole token buffer, level 0 included
+__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ x, void* xs, long long plane, int B, int P0, int L) {
+  const int lane = threadIdx.x & 63;
+  const long long rows = (long long)B * P0;
+  for (long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); i < rows; i += (long long)gridDim.x * 4) {
+    const long long row = (i / P0) * L + (i % P0);   // level-0 rows of stream i / P0
+    st4_split(xs, plane, row * LBM_C + lane * 4, ld4(x + row * LBM_C + lane * 4));
+  }
+}
+
+__global__ __launch_bounds__(256) void pyramid_pool_kernel(float* __restrict__ tok, int B, int h, int w, int L, void* toks,
+                                                           long long toks_plane) {
   // one 64-lane group per output cell (levels 1..3); lane owns 4 channels
   const int lane = threadIdx.x & 63;
   const int P0 = h * w;
@@ -43,19 +54,29 @@ __global__ __launch_bounds__(256) void pyramid_pool_kernel(float* __restrict__ t
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
       }
     const float inv = 1.0f / (float)(s * s);
-    st4(tok + ((long long)b * L + start + o) * LBM_C + lane * 4, make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv));
+    const float4 v = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+    st4(tok + ((long long)b * L + start + o) * LBM_C + lane * 4, v);
+    if (toks) st4_split(toks, toks_plane, ((long long)b * L + start + o) * LBM_C + lane * 4, v);
   }
 }
 
-int pyramid_pool(float* tokens, int B, int h, int w, hipStream_t stream) {
+int pyramid_pool(float* tokens, int B, int h, int w, hipStream_t stream, void* toks, long long toks_plane) {
   LBM_REQUIRE(tokens && B > 0 && h % 8 == 0 && w % 8 == 0, "pyramid_pool: grid %dx%d must be a multiple of 8", h, w);
   const int P0 = h * w;
   const int L = P0 + P0 / 4 + P0 / 16 + P0 / 64;
   long long blocks = ((long long)B * (L - P0) + 3) / 4;
   if (blocks > 16384) blocks = 16384;
   ProfScope prof("pyramid_pool", stream, 0.0, 4.0 * LBM_C * B * ((double)P0 + (L - P0)));
-  hipLaunchKernelGGL(pyramid_pool_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, tokens, B, h, w, L);
-  return check_launch("pyramid_pool");
+  hipLaunchKernelGGL(pyramid_pool_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, tokens, B, h, w, L, toks, toks_plane);
+  if (check_launch("pyramid_pool")) return -1;
+  if (toks) {   // level 0 rows of every stream (levels 1..3 were emitted above)
+    long long rb = ((long long)B * P0 + 3) / 4;
+    if (rb > 32768) rb = 32768;
+    ProfScope prof2("split_rows", stream, 0.0, 8.0 * LBM_C * B * P0);
+    hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)rb), dim3(256), 0, stream, tokens, toks, toks_plane, B, P0, L);
+    return check_launch("split_rows");
+  }
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -170,12 +191,17 @@ int corr_maps(const float* tokens, float* inv_norm, float* F, const float* wmix_
 
 // ------------------------------------------------------------------------------------------------
 // top-k of each row: per-lane sorted candidate list (static registers), then K rounds of a wave arg-max.
-template <int KMAX>
+// WPR waves share one row (each scans a contiguous quarter, the partial top-k lists are merged through LDS by wave 0):
+// with ~1000 rows one wave per row leaves most of the chip idle and is bound by the latency of a 48 KB serial scan.
+template <int KMAX, int WPR>
 __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict__ corr, long long ld, int P, int k, int rows,
                                                        int grid_w, float cell, int* __restrict__ idx_out,
                                                        float* __restrict__ ref_out, float* __restrict__ val_out) {
+  __shared__ float cv[4][16];
+  __shared__ int ci[4][16];
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int wave = threadIdx.x >> 6;
+  const int row = WPR == 1 ? blockIdx.x * 4 + wave : blockIdx.x;
   if (row >= rows) return;
   float lv[KMAX];
   int li[KMAX];
@@ -186,31 +212,36 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
   }
   const float* src = corr + (long long)row * ld;
   auto offer = [&](float v, int i) {
-    if (v > lv[KMAX - 1]) {
+    if (v > lv[KMAX - 1] || (v == lv[KMAX - 1] && i < li[KMAX - 1])) {
       lv[KMAX - 1] = v;
       li[KMAX - 1] = i;
 #pragma unroll
       for (int t = KMAX - 1; t > 0; --t) {
-        if (lv[t] > lv[t - 1]) {
+        if (lv[t] > lv[t - 1] || (lv[t] == lv[t - 1] && li[t] < li[t - 1])) {
           const float tv = lv[t]; lv[t] = lv[t - 1]; lv[t - 1] = tv;
           const int ti = li[t]; li[t] = li[t - 1]; li[t - 1] = ti;
         }
       }
     }
   };
+  // this wave's share of the row, in float4 pieces
   const int nvec = P >> 2;
-  for (int f = lane; f < nvec; f += 64) {
+  const int per = (nvec + WPR - 1) / WPR;
+  const int f0 = WPR == 1 ? 0 : wave * per;
+  const int f1 = WPR == 1 ? nvec : min(nvec, f0 + per);
+  for (int f = f0 + lane; f < f1; f += 64) {
     const float4 v = ld4(src + f * 4);
     offer(v.x, f * 4);
     offer(v.y, f * 4 + 1);
     offer(v.z, f * 4 + 2);
     offer(v.w, f * 4 + 3);
   }
-  for (int i = (nvec << 2) + lane; i < P; i += 64) offer(src[i], i);
+  if (WPR == 1 || wave == WPR - 1)
+    for (int i = (nvec << 2) + lane; i < P; i += 64) offer(src[i], i);
 
-  for (int t = 0; t < k; ++t) {
-    float bv = lv[0];
-    int bi = li[0];
+  auto extract = [&](float& bv, int& bi) {   // wave arg-max of the list heads; the winning lane pops its head
+    bv = lv[0];
+    bi = li[0];
 #pragma unroll
     for (int s = 1; s < 64; s <<= 1) {
       const float ov = __shfl_xor(bv, s);
@@ -220,7 +251,7 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
         bi = oi;
       }
     }
-    if (li[0] == bi) {   // the winning lane pops its head
+    if (li[0] == bi) {
 #pragma unroll
       for (int q = 0; q < KMAX - 1; ++q) {
         lv[q] = lv[q + 1];
@@ -229,16 +260,71 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
       lv[KMAX - 1] = -INFINITY;
       li[KMAX - 1] = 0x7fffffff;
     }
+  };
+  auto emit = [&](int t, float bv, int bi) {
+    const long long o = (long long)row * k + t;
+    idx_out[o] = bi;
+    if (ref_out) {
+      ref_out[o * 2 + 0] = (float)(bi % grid_w) * cell + 0.5f * cell;   // coord_utils.py:20-21
+      ref_out[o * 2 + 1] = (float)(bi / grid_w) * cell + 0.5f * cell;
+    }
+    if (val_out) val_out[o] = bv;
+  };
+
+  if (WPR == 1) {
+    for (int t = 0; t < k; ++t) {
+      float bv;
+      int bi;
+      extract(bv, bi);
+      if (lane == 0) emit(t, bv, bi);
+    }
+    return;
+  }
+  // each wave parks its k best in LDS; wave 0 merges the WPR * k (<= 64) candidates, one per lane
+  for (int t = 0; t < k; ++t) {
+    float bv;
+    int bi;
+    extract(bv, bi);
     if (lane == 0) {
-      const long long o = (long long)row * k + t;
-      idx_out[o] = bi;
-      if (ref_out) {
-        ref_out[o * 2 + 0] = (float)(bi % grid_w) * cell + 0.5f * cell;   // coord_utils.py:20-21
-        ref_out[o * 2 + 1] = (float)(bi / grid_w) * cell + 0.5f * cell;
-      }
-      if (val_out) val_out[o] = bv;
+      cv[wave][t] = bv;
+      ci[wave][t] = bi;
     }
   }
+  __syncthreads();
+  if (wave != 0) return;
+  float mv = -INFINITY;
+  int mi = 0x7fffffff;
+  if (lane < WPR * k) {
+    mv = cv[lane / k][lane % k];
+    mi = ci[lane / k][lane % k];
+  }
+  for (int t = 0; t < k; ++t) {
+    float bv = mv;
+    int bi = mi;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+      const float ov = __shfl_xor(bv, s);
+      const int oi = __shfl_xor(bi, s);
+      if (ov > bv || (ov == bv && oi < bi)) {
+        bv = ov;
+        bi = oi;
+      }
+    }
+    if (mi == bi) {
+      mv = -INFINITY;
+      mi = 0x7fffffff;
+    }
+    if (lane == 0) emit(t, bv, bi);
+  }
+}
+
+template <int KMAX>
+static void launch_topk(bool wide, dim3 grid, hipStream_t stream, const float* corr, long long ld, int P, int k, int rows, int grid_w,
+                        float cell, int* idx_out, float* ref_out, float* val_out) {
+  if (wide)
+    hipLaunchKernelGGL((topk_rows_kernel<KMAX, 4>), grid, dim3(256), 0, stream, corr, ld, P, k, rows, grid_w, cell, idx_out, ref_out, val_out);
+  else
+    hipLaunchKernelGGL((topk_rows_kernel<KMAX, 1>), grid, dim3(256), 0, stream, corr, ld, P, k, rows, grid_w, cell, idx_out, ref_out, val_out);
 }
 
 int topk_rows(const float* corr, long long ld, int P, int k, int rows, int grid_w, int stride_px, int* idx_out,
@@ -247,17 +333,14 @@ int topk_rows(const float* corr, long long ld, int P, int k, int rows, int grid_
   LBM_REQUIRE(corr && idx_out, "topk_rows: null argument");
   LBM_REQUIRE(k >= 1 && k <= 16 && k <= P, "topk_rows: k=%d out of range", k);
   LBM_REQUIRE(ld % 4 == 0 && ((uintptr_t)corr & 15) == 0, "topk_rows: rows must be 16-byte aligned");
-  dim3 grid((rows + 3) / 4), block(256);
+  const bool wide = rows < 4096 && P >= 1024;        // few rows: four waves per row
+  dim3 grid(wide ? rows : (rows + 3) / 4);
   const float cell = (float)stride_px;
   ProfScope prof("topk_rows", stream, 0.0, 4.0 * rows * ((double)P + 4.0 * k));
-  if (k == 1)
-    hipLaunchKernelGGL(topk_rows_kernel<1>, grid, block, 0, stream, corr, ld, P, k, rows, grid_w, cell, idx_out, ref_out, val_out);
-  else if (k <= 4)
-    hipLaunchKernelGGL(topk_rows_kernel<4>, grid, block, 0, stream, corr, ld, P, k, rows, grid_w, cell, idx_out, ref_out, val_out);
-  else if (k <= 9)
-    hipLaunchKernelGGL(topk_rows_kernel<9>, grid, block, 0, stream, corr, ld, P, k, rows, grid_w, cell, idx_out, ref_out, val_out);
-  else
-    hipLaunchKernelGGL(topk_rows_kernel<16>, grid, block, 0, stream, corr, ld, P, k, rows, grid_w, cell, idx_out, ref_out, val_out);
+  if (k == 1) launch_topk<1>(wide, grid, stream, corr, ld, P, k, rows, grid_w, cell, idx_out, ref_out, val_out);
+  else if (k <= 4) launch_topk<4>(wide, grid, stream, corr, ld, P, k, rows, grid_w, cell, idx_out, ref_out, val_out);
+  else if (k <= 9) launch_topk<9>(wide, grid, stream, corr, ld, P, k, rows, grid_w, cell, idx_out, ref_out, val_out);
+  else launch_topk<16>(wide, grid, stream, corr, ld, P, k, rows, grid_w, cell, idx_out, ref_out, val_out);
   return check_launch("topk_rows");
 }
 

@@ -4,7 +4,8 @@
 namespace lbm {
 
 // tokens [B, L, 256] with level 0 in rows [0, h*w); fills rows [h*w, L) (levels 1..3) in place.
-int pyramid_pool(float* tokens, int B, int h, int w, hipStream_t stream);
+// toks (optional): split-plane twin of the whole buffer (all four levels), lo plane toks_plane elements after hi.
+int pyramid_pool(float* tokens, int B, int h, int w, hipStream_t stream, void* toks = nullptr, long long toks_plane = 0);
 
 // inv_norm [B, L] scratch; F [n_layers, B, h*w, 256]; wmix_host = n_layers x 4 corr_conv weights (host memory).
 // split: F is written as the B operand of the split-precision GEMM (per layer: hi planes of all streams, then lo planes)

@@ -56,14 +56,29 @@ class _Conv:
     def __init__(self, w, b, kh, stride, pad, dev):
         self.w = w.to(dev, torch.float32).contiguous()
         self.b = b.to(dev, torch.float32).contiguous()
+        self.ws = hip.SplitWeight(self.w)           # f16 hi/lo planes for the split-precision path
         self.kh, self.stride, self.pad = kh, stride, pad
 
     def __call__(self, x, relu, res=None):
+        """fp32 NHWC in -> fp32 NHWC out on the exact fp32 MFMA."""
         return hip.conv2d_nhwc(x, self.w, self.b, self.kh, self.kh, self.stride, self.pad, relu, res)
+
+    def loader_split(self, x, relu, res=None):
+        """fp32 NHWC in (split in the loader) -> fp32 NHWC out on the f16 matrix cores (the 4-channel RGB stem)."""
+        return hip.conv2d_nhwc(x, self.ws, self.b, self.kh, self.kh, self.stride, self.pad, relu, res)
+
+    def split(self, xs, relu, res=None, want_f32=True, want_split=True, scratch=None):
+        """split NHWC in -> (fp32, split) out; im2col rows gathered by LDS-DMA."""
+        return hip.conv2d_nhwc_ss(xs, self.ws, self.b, self.kh, self.stride, self.pad, relu, res, want_f32, want_split, scratch)
 
 
 class EncoderWeights:
-    def __init__(self, bb):
+    def __init__(self, bb, precision: Optional[str] = None):
+        import os
+        precision = precision or os.environ.get("LBM_AMD_PRECISION", "split")
+        if precision not in ("split", "f32"):
+            raise ValueError("precision must be 'split' or 'f32'")
+        self.precision = precision
         dev = bb.frame_pos_embedding.device
         if dev.type != "cuda":
             raise hip.HipError("the encoder runs on the GPU only: move the model with .cuda() first")
@@ -86,10 +101,14 @@ class EncoderWeights:
                 self.blocks.append((_Conv(_pack_conv(w1), b1, 3, blk.stride, 1, dev), _Conv(_pack_conv(w2), b2, 3, 1, 1, dev), down))
         f32 = lambda t: t.to(dev, torch.float32).contiguous()
         self.proj = [(f32(_f64(p.weight).flatten(1)), f32(_f64(p.bias))) for p in (bb.proj1, bb.proj2, bb.proj3)]
+        self.proj_s = [hip.SplitWeight(pw) for pw, _ in self.proj]
         fw, fb = _fold_bn(bb.fusion[0].weight, bb.fusion[1])
         scale = _f64(bb.fusion[1].weight) / torch.sqrt(_f64(bb.fusion[1].running_var) + bb.fusion[1].eps)
         fb = fb + _f64(bb.fusion[0].bias) * scale
         self.fusion_w, self.fusion_b = f32(fw.flatten(1)), f32(fb)
+        self.fusion_ws = hip.SplitWeight(self.fusion_w)
+        self._scratch = None
+        self.tokens_split: Optional[hip.SplitTensor] = None     # split twin of the last encode() output
         # positional embedding, token-major (P0, 256)
         self.pos = f32(_f64(bb.frame_pos_embedding)[0].permute(1, 2, 0).reshape(self.P0, -1))
 
@@ -104,6 +123,9 @@ class EncoderWeights:
         return self._body(x, add_pos, None)
 
     def _body(self, x: torch.Tensor, add_pos: bool, out: Optional[torch.Tensor]) -> torch.Tensor:
+        if self.precision == "split":
+            return self._body_split(x, add_pos, out)
+        self.tokens_split = None
         B = x.shape[0]
         y = self.stem(x, True)
         y = hip.maxpool3x3s2_nhwc(y)
@@ -124,6 +146,37 @@ class EncoderWeights:
                            strides=(self.P0 * 192, 0, 0, self.L * 256, 0), M=self.P0, N=256, K=192, ldx=192, ldw=192,
                            ldy=256, ldres=256, batch=B)
         hip.pyramid(out, self.h, self.w)
+        return out
+
+
+    def _body_split(self, x: torch.Tensor, add_pos: bool, out: Optional[torch.Tensor]) -> torch.Tensor:
+        """Same network with every contraction on the f16 matrix cores (split operands, fp32-grade)."""
+        B = x.shape[0]
+        if self._scratch is None:
+            self._scratch = torch.empty(32 << 20, device=self.dev, dtype=torch.uint8)    # K-split slabs of small convolutions
+        y = self.stem.loader_split(x, True)
+        y, ys = hip.maxpool3x3s2_nhwc_s(y)
+        feats = []
+        for i, (c1, c2, down) in enumerate(self.blocks):
+            idn = y if down is None else down.split(ys, False, want_split=False, scratch=self._scratch)[0]
+            _, ts = c1.split(ys, True, want_f32=False, scratch=self._scratch)
+            y, ys = c2.split(ts, True, idn, scratch=self._scratch)
+            if i % 2 == 1:
+                feats.append(ys)
+        ps = []
+        for f, pw, (_, pb) in zip(feats, self.proj_s, self.proj):
+            ps.append(hip.linear_ss(f.reshape(-1, f.shape[-1]), pw, pb)[0])
+        cat = hip.upcat_s(ps[0], ps[1], ps[2], B, self.h, self.w)
+        if out is None:
+            out = torch.empty(B, self.L, 256, device=self.dev, dtype=torch.float32)
+        P0 = self.P0
+        hip.linear_ss_raw(A=cat.hi, a_plane=cat.plane, B=self.fusion_ws.hi, b_plane=self.fusion_ws.planes[0].numel(),
+                          bias=self.fusion_b.data_ptr(), Y=out.data_ptr(), res=self.pos.data_ptr() if add_pos else None,
+                          M=P0, N=256, K=192, lda=192, ldb=192, ldy=256, ldres=256, res_div=1, res_mod=0, res_scale=1.0, act=1,
+                          batch=B, sA=P0 * 192, sB=0, sBias=0, sY=self.L * 256, sR=0)
+        if self.tokens_split is None or self.tokens_split.shape != (B, self.L, 256):
+            self.tokens_split = hip.SplitTensor((B, self.L, 256), self.dev)
+        hip.pyramid_s(out, self.tokens_split, self.h, self.w)
         return out
 
 
@@ -301,7 +354,7 @@ class TrackEngine:
         return d
 
     def workspace(self, d: hip.StepDesc) -> torch.Tensor:
-        key = (d.B, d.N, d.M, d.precision)
+        key = (d.B, d.N, d.M, d.precision, bool(d.tokens_split))
         if self._ws is None or self._ws_key != key:
             nbytes = int(hip.load().lbm_hip_step_workspace_bytes(C.byref(d)))
             if nbytes == 0:
@@ -314,7 +367,8 @@ class TrackEngine:
     def step(self, tokens: torch.Tensor, query: torch.Tensor, stream_mem: torch.Tensor, coll_mem: torch.Tensor,
              vis_mask: torch.Tensor, mem_mask: torch.Tensor, ring_head: int = 0, queried: Optional[torch.Tensor] = None,
              update_state: bool = True, img_hw: Optional[Sequence[int]] = None, want_memory: bool = False,
-             want_aux: bool = False, want_corr: bool = False, vis_threshold: float = 0.8) -> Dict[str, torch.Tensor]:
+             want_aux: bool = False, want_corr: bool = False, vis_threshold: float = 0.8,
+             tokens_split: Optional["hip.SplitTensor"] = None) -> Dict[str, torch.Tensor]:
         """tokens (B,L,256) pyramid; query (B,N,256); memories (B,N,M,256) in ring order; masks (B,N,M) bool/uint8."""
         hip._require_gpu()
         if self.w.memory_size != stream_mem.shape[2]:
@@ -327,6 +381,10 @@ class TrackEngine:
         d.ring_head, d.update_state = ring_head, 1 if update_state else 0
         ih, iw = img_hw if img_hw is not None else cfg.input_size
         d.img_h, d.img_w = float(ih), float(iw)
+        if tokens_split is not None and d.precision == 1:
+            if tokens_split.shape != tuple(tokens.shape):
+                raise hip.HipError("tokens_split does not match tokens")
+            d.tokens_split = tokens_split.hi
         ws = self.workspace(d)
         dev = self.dev
         out: Dict[str, torch.Tensor] = {

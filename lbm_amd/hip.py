@@ -26,6 +26,7 @@ EXPORTS = (
     "lbm_hip_preprocess", "lbm_hip_upcat", "lbm_hip_sample_queries", "lbm_hip_step_workspace_bytes",
     "lbm_hip_track_step", "lbm_hip_step_workspace_offset", "lbm_hip_conv2d_nhwc", "lbm_hip_maxpool3x3s2_nhwc",
     "lbm_hip_profile_begin", "lbm_hip_profile_end", "lbm_hip_split_planes", "lbm_hip_debug_set", "lbm_hip_linear_ss",
+    "lbm_hip_conv2d_nhwc_ss", "lbm_hip_maxpool3x3s2_nhwc_s", "lbm_hip_upcat_s", "lbm_hip_pyramid_s",
 )
 
 
@@ -72,7 +73,7 @@ class StepDesc(C.Structure):
                 ("corr_mix", C.c_float * (MAX_LAYERS * 4)), ("corr_bias", C.c_float * MAX_LAYERS),
                 ("weights", C.POINTER(C.c_void_p)), ("n_weights", C.c_int32),
                 ("precision", C.c_int32), ("weights_lo", C.POINTER(C.c_void_p)),
-                ("tokens", C.c_void_p), ("query", C.c_void_p), ("stream_mem", C.c_void_p), ("coll_mem", C.c_void_p),
+                ("tokens", C.c_void_p), ("tokens_split", C.c_void_p), ("query", C.c_void_p), ("stream_mem", C.c_void_p), ("coll_mem", C.c_void_p),
                 ("vis_mask", C.c_void_p), ("mem_mask", C.c_void_p), ("queried", C.c_void_p),
                 ("coords", C.c_void_p), ("vis", C.c_void_p), ("rho", C.c_void_p), ("offset", C.c_void_p),
                 ("stream_out", C.c_void_p), ("coll_out", C.c_void_p),
@@ -137,6 +138,11 @@ def load() -> C.CDLL:
     lib.lbm_hip_track_step.argtypes = [C.POINTER(StepDesc), C.c_void_p]
     lib.lbm_hip_conv2d_nhwc.argtypes = [C.c_void_p] * 6 + [C.c_int32] * 11 + [C.c_void_p]
     lib.lbm_hip_maxpool3x3s2_nhwc.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p]
+    lib.lbm_hip_conv2d_nhwc_ss.argtypes = ([C.c_void_p, C.c_int64] + [C.c_void_p] * 6 + [C.c_int64, C.c_void_p, C.c_void_p, C.c_uint64] +
+                                           [C.c_int32] * 11 + [C.c_void_p])
+    lib.lbm_hip_maxpool3x3s2_nhwc_s.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64] + [C.c_int32] * 4 + [C.c_void_p]
+    lib.lbm_hip_upcat_s.argtypes = [C.c_void_p] * 5 + [C.c_int64] + [C.c_int32] * 3 + [C.c_void_p]
+    lib.lbm_hip_pyramid_s.argtypes = [C.c_void_p, C.c_void_p, C.c_int64] + [C.c_int32] * 3 + [C.c_void_p]
     lib.lbm_hip_linear_ss.argtypes = [C.POINTER(LinearSSDesc), C.c_void_p]
     lib.lbm_hip_split_planes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.lbm_hip_profile_end.argtypes = [C.POINTER(ProfileEntry), C.c_int32]
@@ -211,6 +217,92 @@ class SplitWeight:
     @property
     def lo(self) -> int:
         return self.planes[1].data_ptr()
+
+
+class SplitTensor:
+    """An activation stored as two f16 planes (hi, lo * 2^11): `planes` has shape (2, *shape)."""
+
+    def __init__(self, shape, device):
+        self.shape = tuple(shape)
+        self.planes = torch.empty((2,) + self.shape, device=device, dtype=torch.float16)
+
+    @property
+    def hi(self) -> int:
+        return self.planes.data_ptr()
+
+    @property
+    def plane(self) -> int:
+        return self.planes[0].numel()
+
+    def float(self) -> torch.Tensor:
+        return self.planes[0].float() + self.planes[1].float() / 2048.0
+
+    def reshape(self, *shape) -> "SplitTensor":
+        t = SplitTensor.__new__(SplitTensor)
+        t.planes = self.planes.view(2, *shape)
+        t.shape = tuple(t.planes.shape[1:])
+        return t
+
+
+_zeros: Dict[str, torch.Tensor] = {}
+
+
+def zero_page(device) -> int:
+    key = str(device)
+    if key not in _zeros:
+        _zeros[key] = torch.zeros(256, device=device, dtype=torch.uint8)
+    return _zeros[key].data_ptr()
+
+
+def conv2d_nhwc_ss(x: "SplitTensor", w: "SplitWeight", bias: torch.Tensor, kh: int, stride: int, pad: int, relu: bool,
+                   res: Optional[torch.Tensor] = None, want_f32: bool = True, want_split: bool = True,
+                   scratch: Optional[torch.Tensor] = None):
+    """Split-precision NHWC convolution: x (B,H,W,Cin) split, packed weights split -> (y fp32 | None, ys SplitTensor | None)."""
+    _require_gpu()
+    B, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    Ho = (H + 2 * pad - kh) // stride + 1
+    Wo = (W + 2 * pad - kh) // stride + 1
+    dev = x.planes.device
+    y = torch.empty(B, Ho, Wo, Cout, device=dev, dtype=torch.float32) if want_f32 else None
+    ys = SplitTensor((B, Ho, Wo, Cout), dev) if want_split else None
+    _check(load().lbm_hip_conv2d_nhwc_ss(x.hi, x.plane, w.hi, w.lo, _p(bias), _p(res), _p(y), ys.hi if ys else None,
+                                         ys.plane if ys else 0, zero_page(dev), _p(scratch, None) if scratch is not None else None,
+                                         scratch.numel() * scratch.element_size() if scratch is not None else 0,
+                                         B, H, W, Cin, Cout, kh, kh, stride, pad, 1 if relu else 0, w.shape[1], _stream()),
+           "lbm_hip_conv2d_nhwc_ss")
+    return y, ys
+
+
+def maxpool3x3s2_nhwc_s(x: torch.Tensor):
+    _require_gpu()
+    B, H, W, Cc = x.shape
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    y = torch.empty(B, Ho, Wo, Cc, device=x.device, dtype=torch.float32)
+    ys = SplitTensor((B, Ho, Wo, Cc), x.device)
+    _check(load().lbm_hip_maxpool3x3s2_nhwc_s(_p(x), _p(y), ys.hi, ys.plane, B, H, W, Cc, _stream()), "lbm_hip_maxpool3x3s2_nhwc_s")
+    return y, ys
+
+
+def upcat_s(p1, p2, p3, B, h, w) -> "SplitTensor":
+    _require_gpu()
+    outs = SplitTensor((B * h * w, 192), p1.device)
+    _check(load().lbm_hip_upcat_s(_p(p1), _p(p2), _p(p3), None, outs.hi, outs.plane, B, h, w, _stream()), "lbm_hip_upcat_s")
+    return outs
+
+
+def pyramid_s(tokens: torch.Tensor, tokens_s: "SplitTensor", h: int, w: int) -> None:
+    _require_gpu()
+    _check(load().lbm_hip_pyramid_s(_p(tokens), tokens_s.hi, tokens_s.plane, tokens.shape[0], h, w, _stream()), "lbm_hip_pyramid_s")
+
+
+def linear_ss_raw(**kw) -> None:
+    """lbm_hip_linear_ss with the descriptor fields given by name (pointers as ints)."""
+    _require_gpu()
+    d = LinearSSDesc()
+    for k, v in kw.items():
+        setattr(d, k, v)
+    _check(load().lbm_hip_linear_ss(C.byref(d), _stream()), "lbm_hip_linear_ss")
 
 
 def linear_ss(a: "SplitWeight", b: "SplitWeight", bias=None, act: int = 0, res=None, res_scale: float = 1.0,

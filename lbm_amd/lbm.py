@@ -44,6 +44,11 @@ class LBM(nn.Module):
                                           n_neighbor=self.num_neighbors, n_mem=self.memory_size, n_topk=self.top_k_regions,
                                           dropout=self.dropout)
 
+    def set_precision(self, precision) -> None:
+        """"split" (default): contractions on the f16 matrix cores with split operands, fp32-grade; "f32": exact fp32 MFMA."""
+        self.backbone.set_precision(precision)
+        self.transformer.set_precision(precision)
+
     # lbm.py:70-87 — resize the past time embeddings by linear interpolation (align_corners=True), keep "now".
     def set_memory_size(self, memory_size: int) -> None:
         for layer in self.transformer.layers:

@@ -160,7 +160,8 @@ class LBM_online(LBM):
         tok = self.backbone.encode_tokens(frames, tokens)
         out = self.transformer.get_engine().step(tok, self.query, self._stream, self._coll, self._vis, self._mem,
                                                  ring_head=self._head, queried=None, update_state=True, img_hw=(H, W),
-                                                 vis_threshold=self.visibility_treshold)
+                                                 vis_threshold=self.visibility_treshold,
+                                                 tokens_split=self.backbone.last_tokens_split)
         self._head = (self._head + 1) % self.memory_size
         self.t += 1
         self.last_logits = (out["vis"], out["rho"])

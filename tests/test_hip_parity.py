@@ -116,10 +116,11 @@ def test_pyramid_and_corr_maps_against_reference_correlation(hip, golden):
     _cmp(corr, gold["corr"], rtol=1e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("rows", [37, 4100])          # four waves per row / one wave per row
 @pytest.mark.parametrize("k", [1, 4, 9, 16])
-def test_topk_is_exact_with_lowest_index_ties(hip, k):
+def test_topk_is_exact_with_lowest_index_ties(hip, k, rows):
     r = np.random.default_rng(k)
-    rows, P = 37, 3072
+    P = 3072
     c = r.normal(size=(rows, P)).astype(np.float32)
     c[:, 100] = c[:, 2000] = 50.0          # exact ties: the lower index must win
     c[3, :] = 1.0                          # a fully tied row
@@ -311,7 +312,7 @@ def test_sequence_ring_buffer_state_against_reference_golden(hip, golden, precis
 # encoder and the online wrapper
 # ---------------------------------------------------------------------------------------------------------------
 
-def _online(cfg_kw, seed=42):
+def _online(cfg_kw, seed=42, precision=None):
     from lbm_amd.config import LBMConfig
     from lbm_amd.lbm_online import LBM_online
     from lbm_amd.synth import synthetic_state_dict
@@ -319,13 +320,15 @@ def _online(cfg_kw, seed=42):
     model = LBM_online(cfg.to_namespace())
     sd = synthetic_state_dict(model, seed=seed)
     model.load_state_dict(sd, strict=True)
+    model.set_precision(precision)
     return model.cuda().eval(), sd
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("size,frame", [((96, 128), (120, 160)), ((384, 512), (480, 854))])
-def test_encoder_against_oracle(hip, size, frame):
+def test_encoder_against_oracle(hip, size, frame, precision):
     from lbm_amd.synth import synthetic_video
-    model, sd = _online(dict(input_size=size, memory_size=4))
+    model, sd = _online(dict(input_size=size, memory_size=4), precision=precision)
     g = ref.Geometry(size=size, memory_size=4)
     video = synthetic_video(2, frame[0], frame[1], seed=9)
     frames = video[0]                                                    # (2,3,H,W): a batch of two frames
@@ -338,12 +341,18 @@ def test_encoder_against_oracle(hip, size, frame):
     _cmp(got, want, rtol=1e-3, atol=1e-3)
     want_pyr = ref.pyramid(want)
     _cmp(tok[:, g.h * g.w: g.h * g.w + (g.h * g.w) // 4], want_pyr[1], rtol=1e-3, atol=1e-3)
+    ts = model.backbone.last_tokens_split
+    if precision == "split":
+        _cmp(ts.float(), tok, rtol=1e-6, atol=1e-6)      # the split twin handed to the tracker is the same tensor
+    else:
+        assert ts is None
 
 
-def test_online_tracker_against_oracle_sequence(hip):
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_online_tracker_against_oracle_sequence(hip, precision):
     """LBM_online.init / online_forward (lbm_online.py:27-158) end to end, encoder included, published geometry."""
     from lbm_amd.synth import synthetic_video, grid_queries
-    model, sd = _online(dict(input_size=(384, 512), memory_size=12))
+    model, sd = _online(dict(input_size=(384, 512), memory_size=12), precision=precision)
     g = ref.Geometry(size=(384, 512), memory_size=12)
     T, H, W = 5, 480, 854
     video = synthetic_video(T, H, W, seed=4)

@@ -206,7 +206,7 @@ struct Step {
     } else {
       int nsplit = 1;
       const long long tiles = (long long)((M + 63) / 64) * (LBM_C / 64);
-      while (nsplit < 8 && tiles * nsplit < 192 && K / (nsplit * 2) >= 128 && (K / (nsplit * 2)) % 32 == 0) nsplit *= 2;
+      while (nsplit < 8 && tiles * nsplit < 192 && K / (nsplit * 2) >= 256 && (K / (nsplit * 2)) % 32 == 0) nsplit *= 2;
       LBM_REQUIRE((unsigned long long)nsplit * M * LBM_C * sizeof(float) <= pre_bytes, "step: K-split slabs exceed the scratch buffer");
       GemmSSArgs a;
       a.A = X.s; a.a_plane = X.plane; a.lda = ldx;

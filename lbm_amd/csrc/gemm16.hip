@@ -457,7 +457,23 @@ __device__ __forceinline__ void wait_vmcnt() {
   else static_assert(N < 0, "unsupported vmcnt");
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, bool CONV>
+// compile-time unrolled consumer loop of the FULL variant: stage KT is multiplied once everything issued up to it
+// has landed (the (STAGES - 1 - KT) younger stages may still be in flight); no buffer is ever reused, so one
+// barrier per stage suffices.
+template <int KT, int STAGES, int PPW, typename F>
+__device__ __forceinline__ void pf_steps(F& f) {
+  if constexpr (KT < STAGES) {
+    wait_vmcnt<(STAGES - 1 - KT) * PPW>();
+    __builtin_amdgcn_s_barrier();
+    f(KT);
+    pf_steps<KT + 1, STAGES, PPW>(f);
+  }
+}
+
+// FULL: K / 32 == STAGES exactly; the DMA of the whole K extent is issued up front (STAGES x stage bytes of LDS, one
+// workgroup per CU).  This is the small-problem variant: with ~1 workgroup per CU nothing else hides the DMA
+// latency, so it is paid once per workgroup instead of once per chunk.
+template <int BM, int BN, int WM, int WN, int STAGES, bool CONV, bool FULL = false>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_ss_kernel(GemmSSDev a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // LDS-DMA builtins and s_waitcnt asm exist on the device side only
   constexpr int NW = WM * WN;
@@ -550,8 +566,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_ss_kernel(GemmSSDev a) {
 
   const int nk = a.K / 32;
 #pragma unroll
-  for (int s = 0; s < STAGES - 1; ++s)
-    if (s < nk) issue(s, s);
+  for (int s = 0; s < (FULL ? STAGES : STAGES - 1); ++s)
+    if (FULL || s < nk) issue(s, s);
 
   // fragment byte offsets inside a plane: row * 64 + ((c ^ ((row >> 2) & 3)) * 16), c = 2 s + h
   int offA[TM][2], offB[TN][2];
@@ -568,16 +584,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_ss_kernel(GemmSSDev a) {
     for (int s = 0; s < 2; ++s) offB[j][s] = row * 64 + (((2 * s + h) ^ ((row >> 2) & 3)) << 4);
   }
 
-  for (int kt = 0; kt < nk; ++kt) {
-    const int pre = kt + STAGES - 1;
-    if (pre < nk && !(a.dbg & 1)) {
-      issue(pre % STAGES, pre);
-      wait_vmcnt<(STAGES - 1) * PPW>();        // everything but the STAGES-1 newest stages has landed
-    } else {
-      wait_vmcnt<0>();
-    }
-    __builtin_amdgcn_s_barrier();
-    const unsigned char* Ah = lds + (kt % STAGES) * STAGE;
+  auto compute = [&](int stage) {
+    const unsigned char* Ah = lds + stage * STAGE;
     const unsigned char* Al = Ah + PLANE_A;
     const unsigned char* Bh = Al + PLANE_A;
     const unsigned char* Bl = Bh + PLANE_B;
@@ -610,9 +618,24 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_ss_kernel(GemmSSDev a) {
           }
       }
     }
-    // all waves must be done reading this stage before the next iteration's DMA overwrites it
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+  };
+  if constexpr (FULL) {
+    pf_steps<0, STAGES, PPW>(compute);
+  } else {
+    for (int kt = 0; kt < nk; ++kt) {
+      const int pre = kt + STAGES - 1;
+      if (pre < nk && !(a.dbg & 1)) {
+        issue(pre % STAGES, pre);
+        wait_vmcnt<(STAGES - 1) * PPW>();        // everything but the STAGES-1 newest stages has landed
+      } else {
+        wait_vmcnt<0>();
+      }
+      __builtin_amdgcn_s_barrier();
+      compute(kt % STAGES);
+      // all waves must be done reading this stage before the next iteration's DMA overwrites it
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
   }
 
   // ---- epilogue ----
@@ -657,18 +680,35 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_ss_kernel(GemmSSDev a) {
 #endif
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, bool CONV = false>
+template <int BM, int BN, int WM, int WN, int STAGES, bool CONV = false, bool FULL = false>
 static int launch_ss(const GemmSSDev& d, int batch, hipStream_t stream) {
   dim3 grid((d.N + BN - 1) / BN, (d.M + BM - 1) / BM, batch);
-  static const std::string name = std::string(CONV ? "conv_ss<" : "gemm_ss<") + std::to_string(BM) + "," + std::to_string(BN) + "," + std::to_string(WM) +
+  static const std::string name = std::string(CONV ? "conv_ss" : "gemm_ss") + (FULL ? "_full<" : "<") + std::to_string(BM) + "," + std::to_string(BN) + "," + std::to_string(WM) +
                                   "," + std::to_string(WN) + "," + std::to_string(STAGES) + ">";
   const double mnk = (double)d.M * d.N * d.K * batch;
   ProfScope prof(name.c_str(), stream, 2.0 * mnk,
                  4.0 * ((double)d.M * d.K * batch + (double)d.N * d.K * (d.sB || batch == 1 ? batch : 1) +
                         (double)d.M * d.N * batch * ((d.Y ? 1 : 0) + (d.Ys ? 1 : 0) + (d.res ? 1 : 0))));
-  hipLaunchKernelGGL((gemm_ss_kernel<BM, BN, WM, WN, STAGES, CONV>), grid, dim3(WM * WN * 64), 0, stream, d);
+  hipLaunchKernelGGL((gemm_ss_kernel<BM, BN, WM, WN, STAGES, CONV, FULL>), grid, dim3(WM * WN * 64), 0, stream, d);
   return check_launch(CONV ? "conv_ss" : "gemm_ss");
 }
+
+// 64x64 tiles with the whole K extent prefetched (K / 32 chunks resident): the variant for grids of <= ~2 workgroups per CU
+template <bool CONV>
+static int launch_full(const GemmSSDev& d, int batch, hipStream_t stream, bool* handled) {
+  *handled = true;
+  switch (d.K / 32) {
+    case 2: return launch_ss<64, 64, 2, 2, 2, CONV, true>(d, batch, stream);
+    case 4: return launch_ss<64, 64, 2, 2, 4, CONV, true>(d, batch, stream);
+    case 6: return launch_ss<64, 64, 2, 2, 6, CONV, true>(d, batch, stream);
+    case 8: return launch_ss<64, 64, 2, 2, 8, CONV, true>(d, batch, stream);
+    case 9: return launch_ss<64, 64, 2, 2, 9, CONV, true>(d, batch, stream);
+    default: break;
+  }
+  *handled = false;
+  return 0;
+}
+static bool full_ok(int nk) { return nk == 2 || nk == 4 || nk == 6 || nk == 8 || nk == 9; }
 
 // out = relu?(sum of K-split slabs + bias + res) as fp32 and / or split planes (the epilogue of a K-split convolution)
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int nslab, long long slab_stride,
@@ -723,20 +763,33 @@ int conv2d_nhwc_ss(const ConvSSArgs& c, hipStream_t stream) {
   const long long big = ((M + 127) / 128) * ((c.Cout + 127) / 128);
   const long long mid = ((M + 63) / 64) * ((c.Cout + 63) / 64);
   int nsplit = 1;
-  if (c.scratch != nullptr) {
-    while (nsplit < 16 && mid * nsplit < 192 && nk % (nsplit * 2) == 0 && nk / (nsplit * 2) >= 4 &&
-           (unsigned long long)(nsplit * 2) * M * c.Cout * sizeof(float) <= c.scratch_bytes)
-      nsplit *= 2;
+  if (c.scratch != nullptr && mid <= 320) {
+    // few output pixels: cut K into chunks of at most 9 x 32 that the full-prefetch kernel keeps resident in LDS
+    for (int cand = 1; cand <= 16; ++cand) {
+      if (nk % cand != 0 || (unsigned long long)cand * M * c.Cout * sizeof(float) > c.scratch_bytes) continue;
+      if (full_ok(nk / cand)) {
+        nsplit = cand;
+        if (mid * cand >= 192) break;
+      }
+    }
+    if (!full_ok(nk / nsplit)) nsplit = 1;
   }
-  int rc;
   if (nsplit == 1) {
     d.bias = c.bias; d.res = c.res; d.act = c.relu ? ACT_RELU_POST : ACT_NONE;
     d.Y = c.Y; d.Ys = (_Float16*)c.Ys; d.ys_plane = c.ys_plane; d.kt0_per_z = 0;
-    rc = (big >= 128 && c.Cout > 64) ? launch_ss<128, 128, 2, 4, 2, true>(d, 1, stream) : launch_ss<64, 64, 2, 2, 2, true>(d, 1, stream);
-    return rc;
+    if (mid <= 640 && full_ok(nk)) {
+      bool handled;
+      const int rc = launch_full<true>(d, 1, stream, &handled);
+      if (handled) return rc;
+    }
+    return (big >= 128 && c.Cout > 64) ? launch_ss<128, 128, 2, 4, 2, true>(d, 1, stream) : launch_ss<64, 64, 2, 2, 2, true>(d, 1, stream);
   }
   d.Y = (float*)c.scratch; d.sY = M * c.Cout; d.K = K / nsplit; d.kt0_per_z = nk / nsplit; d.act = ACT_NONE;
-  if (launch_ss<64, 64, 2, 2, 2, true>(d, nsplit, stream)) return -1;
+  {
+    bool handled;
+    if (launch_full<true>(d, nsplit, stream, &handled)) return -1;
+    if (!handled && launch_ss<64, 64, 2, 2, 2, true>(d, nsplit, stream)) return -1;
+  }
   const long long total4 = M * c.Cout / 4;
   long long blocks = (total4 + 255) / 256;
   if (blocks > 65535) blocks = 65535;
@@ -767,7 +820,13 @@ int gemm_ss(const GemmSSArgs& a, hipStream_t stream) {
   d.dbg = g_dbg16;
   const long long big = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.batch;
   int t = g_force_tile16;
-  if (t == 0) t = (big >= 128 && a.N > 64) ? 3 : 2;   // measured: scripts/gemm_bench.py
+  const long long mid = (long long)((a.M + 63) / 64) * ((a.N + 63) / 64) * a.batch;
+  if ((t == 0 && mid <= 640 && full_ok(a.K / 32)) || t == 20) {
+    bool handled;
+    const int rc = launch_full<false>(d, a.batch, stream, &handled);
+    if (handled) return rc;
+  }
+  if (t == 0 || t == 20) t = (big >= 128 && a.N > 64) ? 3 : 2;   // measured: scripts/gemm_bench.py
   switch (t) {
     case 1: return launch_ss<128, 128, 2, 2, 2>(d, a.batch, stream);
     case 2: return launch_ss<64, 64, 2, 2, 2>(d, a.batch, stream);

@@ -116,6 +116,9 @@ def main():
         dist.init_process_group(backend="nccl", device_id=device)
 
     from lbm_amd import hip
+    for kv in os.environ.get("LBM_DEBUG_SET", "").split(","):        # tuning knobs, e.g. LBM_DEBUG_SET=3:4
+        if kv:
+            hip.load().lbm_hip_debug_set(int(kv.split(":")[0]), int(kv.split(":")[1]))
     model, sd = build_model(wl, device)
     video_cpu, pts_cpu = make_inputs(wl, rank)
     video = video_cpu.to(device)                       # (B,T,3,H,W) resident in HBM

@@ -1,4 +1,4 @@
-// Single-query multi-head attention read-out, one wave per point.
+// Single-query multi-head attention read-out over a short per-point sequence.
 //
 // Restates nn.MultiheadAttention for a length-1 query (transformer.py:272, 294, 333) without ever
 // projecting the keys/values:  score_jh = u_h · (seq_j + temb_j)   with u_h = Wk_hᵀ (Wq_h x + bq_h)/8
@@ -8,82 +8,180 @@
 // ring buffer, or the k lattice tokens) is therefore read exactly once from HBM: 2·M·C·4 bytes per point
 // and layer for the two memories — the algorithmic minimum of SURVEY §8(d).
 //
-// Lane mapping: 16 lanes per head (head = lane >> 4); lane c of a group owns channels {64 i + 4 c .. +3}.
-// Each load instruction therefore covers 256 contiguous bytes per group; score partials are reduced
-// inside the 16-lane DPP row (no LDS).  Softmax is online (running max / sum), so any S works.
+// Lane mapping: a wave reads one 1 KiB sequence row per load instruction, lane l owning channels 4l .. 4l+3
+// (every byte fetched once, 16 B per lane, fully coalesced).  Four slots are in flight per wave; their
+// 4 slots x 4 heads = 16 partial dot products are summed over the wave by a butterfly reduce-scatter
+// (17 cross-lane moves instead of 96) and come back as wave-uniform scalars, so the soft-max bookkeeping
+// is shared by all lanes.  Softmax is online (running max / sum), so any S works.
+// WPP = 4 (few points): the four waves of a workgroup share one point, each taking every fourth slot, and merge
+// their (max, sum, accumulator) states through LDS — with ~1000 points one wave per point leaves the chip idle.
 #include "attn.hpp"
 
 namespace lbm {
 
-__global__ __launch_bounds__(256) void attn_readout_kernel(AttnArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= a.R) return;
-  const int g = lane >> 4;
-  const int c = lane & 15;
-
-  float4 u[4];
-  const float* up = a.U + ((long long)row * LBM_HEADS + g) * LBM_C + c * 4;
+// sum p[0..15] over the 64 lanes; afterwards tot[q] (wave-uniform) holds the total of p[q]
+__device__ __forceinline__ void reduce16(const float (&p)[16], float (&tot)[16], int lane) {
+  float a8[8], a4[4], a2[2], a1;
+  const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) u[i] = ld4(up + i * 64);
+  for (int i = 0; i < 8; ++i) a8[i] = (b5 ? p[i + 8] : p[i]) + __shfl_xor(b5 ? p[i] : p[i + 8], 32);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a4[i] = (b4 ? a8[i + 4] : a8[i]) + __shfl_xor(b4 ? a8[i] : a8[i + 4], 16);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) a2[i] = (b3 ? a4[i + 2] : a4[i]) + __shfl_xor(b3 ? a4[i] : a4[i + 2], 8);
+  a1 = (b2 ? a2[1] : a2[0]) + __shfl_xor(b2 ? a2[0] : a2[1], 4);
+  a1 += __shfl_xor(a1, 2);
+  a1 += __shfl_xor(a1, 1);
+  // lane with bits (5,4,3,2) = (q3,q2,q1,q0) holds the total of index q = 8 q3 + 4 q2 + 2 q1 + q0
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int srcl = ((q & 8) ? 32 : 0) | ((q & 4) ? 16 : 0) | ((q & 2) ? 8 : 0) | ((q & 1) ? 4 : 0);
+    tot[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a1), srcl));
+  }
+}
 
-  const float* sp = a.seq + (long long)row * a.point_stride + c * 4;
+template <int WPP>
+__global__ __launch_bounds__(256) void attn_readout_kernel(AttnArgs a) {
+  __shared__ float sm_acc[WPP == 1 ? 1 : 4][LBM_HEADS][LBM_C];
+  __shared__ float sm_ml[WPP == 1 ? 1 : 4][2][LBM_HEADS];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int row = WPP == 1 ? blockIdx.x * 4 + wave : blockIdx.x;
+  if (row >= a.R) return;
+
+  float4 u[LBM_HEADS];
+#pragma unroll
+  for (int hh = 0; hh < LBM_HEADS; ++hh) u[hh] = ld4(a.U + ((long long)row * LBM_HEADS + hh) * LBM_C + lane * 4);
+
+  const float* sp = a.seq + (long long)row * a.point_stride + lane * 4;
   const uint8_t* ma = a.mask_a ? a.mask_a + (long long)row * a.S : nullptr;
   const uint8_t* mb = a.mask_b ? a.mask_b + (long long)row * a.S : nullptr;
 
-  float m = -INFINITY, l = 0.f;
-  float4 acc[4];
+  float m[LBM_HEADS], l[LBM_HEADS];
+  float4 acc[LBM_HEADS];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int hh = 0; hh < LBM_HEADS; ++hh) {
+    m[hh] = -INFINITY;
+    l[hh] = 0.f;
+    acc[hh] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
 
-#pragma unroll 2
-  for (int j = 0; j < a.S; ++j) {
-    int phys = a.ring_head + j;
-    if (phys >= a.S) phys -= a.S;
-    bool ignore = false;
-    if (ma) ignore |= ma[phys] != 0;
-    if (mb) ignore |= mb[phys] != 0;
+  // this wave's slots: j0, j0 + WPP, ...  in groups of four; the loads of group g + 1 are issued before group g is
+  // reduced, so two groups (8 KiB per wave) are in flight while the soft-max arithmetic runs
+  const int step = WPP;
+  const int jb0 = WPP == 1 ? 0 : wave;
+  float4 vn[4];
+  bool usen[4];
+  auto fetch = [&](int jb) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int j = jb + g * step;
+      const bool in = j < a.S;
+      int phys = a.ring_head + (in ? j : 0);
+      if (phys >= a.S) phys -= a.S;
+      bool ignore = !in;
+      if (ma) ignore |= ma[phys] != 0;
+      if (mb) ignore |= mb[phys] != 0;
+      usen[g] = !ignore;
+      vn[g] = ld4(sp + (long long)phys * a.slot_stride);
+    }
+  };
+  if (jb0 < a.S) fetch(jb0);
+  for (int jb = jb0; jb < a.S; jb += 4 * step) {
     float4 v[4];
+    bool use[4];
+    float p[16];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = ld4(sp + (long long)phys * a.slot_stride + i * 64);
-    float part = 0.f;
-    if (a.temb) {
-      const float* tp = a.temb + (long long)j * LBM_C + c * 4;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float4 t = ld4(tp + i * 64);
-        part += u[i].x * (v[i].x + t.x) + u[i].y * (v[i].y + t.y) + u[i].z * (v[i].z + t.z) + u[i].w * (v[i].w + t.w);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) part += u[i].x * v[i].x + u[i].y * v[i].y + u[i].z * v[i].z + u[i].w * v[i].w;
+    for (int g = 0; g < 4; ++g) {
+      v[g] = vn[g];
+      use[g] = usen[g];
     }
-    const float s = row16_sum(part);
-    if (!ignore) {   // wave-uniform: the masks are per (row, slot)
-      const float mn = fmaxf(m, s);
-      const float sc = expf(m - mn);
-      const float p = expf(s - mn);
-      l = l * sc + p;
+    if (jb + 4 * step < a.S) fetch(jb + 4 * step);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        acc[i].x = acc[i].x * sc + p * v[i].x;
-        acc[i].y = acc[i].y * sc + p * v[i].y;
-        acc[i].z = acc[i].z * sc + p * v[i].z;
-        acc[i].w = acc[i].w * sc + p * v[i].w;
+    for (int g = 0; g < 4; ++g) {
+      const int j = jb + g * step;
+      float4 kx = v[g];
+      if (a.temb) {
+        const float4 t = ld4(a.temb + (long long)(j < a.S ? j : 0) * LBM_C + lane * 4);
+        kx = make_float4(kx.x + t.x, kx.y + t.y, kx.z + t.z, kx.w + t.w);
       }
-      m = mn;
+#pragma unroll
+      for (int hh = 0; hh < LBM_HEADS; ++hh) p[g * 4 + hh] = u[hh].x * kx.x + u[hh].y * kx.y + u[hh].z * kx.z + u[hh].w * kx.w;
+    }
+    float s[16];
+    reduce16(p, s, lane);
+#pragma unroll
+    for (int hh = 0; hh < LBM_HEADS; ++hh) {
+      float mn = m[hh];
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        if (use[g]) mn = fmaxf(mn, s[g * 4 + hh]);
+      if (mn == -INFINITY) continue;             // nothing attended so far (wave-uniform)
+      const float sc = expf(m[hh] - mn);         // m = -inf -> 0
+      float ls = l[hh] * sc;
+      float4 ac = make_float4(acc[hh].x * sc, acc[hh].y * sc, acc[hh].z * sc, acc[hh].w * sc);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if (use[g]) {                            // wave-uniform: masks are per (row, slot)
+          const float w = expf(s[g * 4 + hh] - mn);
+          ls += w;
+          ac.x += w * v[g].x; ac.y += w * v[g].y; ac.z += w * v[g].z; ac.w += w * v[g].w;
+        }
+      }
+      m[hh] = mn;
+      l[hh] = ls;
+      acc[hh] = ac;
     }
   }
-  const float inv = l > 0.f ? 1.0f / l : 0.f;
-  const long long oo = ((long long)row * LBM_HEADS + g) * LBM_C + c * 4;
+
+  if (WPP > 1) {   // merge the four waves' online-softmax states
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float4 v = make_float4(acc[i].x * inv, acc[i].y * inv, acc[i].z * inv, acc[i].w * inv);
-    if (a.out) st4(a.out + oo + i * 64, v);
-    if (a.out_s) st4_split(a.out_s, a.out_plane, oo + i * 64, v);
+    for (int hh = 0; hh < LBM_HEADS; ++hh) {
+      st4(&sm_acc[wave][hh][lane * 4], acc[hh]);
+      if (lane == 0) {
+        sm_ml[wave][0][hh] = m[hh];
+        sm_ml[wave][1][hh] = l[hh];
+      }
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int hh = 0; hh < LBM_HEADS; ++hh) {
+      float mm = -INFINITY;
+#pragma unroll
+      for (int w2 = 0; w2 < 4; ++w2) mm = fmaxf(mm, sm_ml[w2][0][hh]);
+      float ls = 0.f;
+      float4 ac = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (mm != -INFINITY) {
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2) {
+          const float mw = sm_ml[w2][0][hh];
+          if (mw == -INFINITY) continue;
+          const float sc = expf(mw - mm);
+          ls += sm_ml[w2][1][hh] * sc;
+          const float4 q = ld4(&sm_acc[w2][hh][lane * 4]);
+          ac.x += q.x * sc; ac.y += q.y * sc; ac.z += q.z * sc; ac.w += q.w * sc;
+        }
+      }
+      m[hh] = mm;
+      l[hh] = ls;
+      acc[hh] = ac;
+    }
   }
-  if (a.valid && lane == 0) a.valid[row] = l > 0.f ? 1 : 0;
+
+#pragma unroll
+  for (int hh = 0; hh < LBM_HEADS; ++hh) {
+    const float inv = l[hh] > 0.f ? 1.0f / l[hh] : 0.f;
+    const float4 o = make_float4(acc[hh].x * inv, acc[hh].y * inv, acc[hh].z * inv, acc[hh].w * inv);
+    const long long oo = ((long long)row * LBM_HEADS + hh) * LBM_C + lane * 4;
+    if (a.out) st4(a.out + oo, o);
+    if (a.out_s) st4_split(a.out_s, a.out_plane, oo, o);
+  }
+  if (a.valid && lane == 0) a.valid[row] = l[0] > 0.f ? 1 : 0;
 }
+
+static int g_attn_mode = 0;   // tuning knob: 0 auto, 1 = one wave per point, 4 = four waves per point
+void attn_force_mode(int m) { g_attn_mode = m; }
 
 int attn_readout(const AttnArgs& a, hipStream_t stream) {
   if (a.R == 0) return 0;
@@ -94,7 +192,11 @@ int attn_readout(const AttnArgs& a, hipStream_t stream) {
   // algorithmic traffic: the S sequence rows once, 4 per-head queries in, 4 per-head read-outs out, the masks
   ProfScope prof("attn_readout", stream, (double)a.R * a.S * 4.0 * LBM_C * 4,
                  (double)a.R * (4.0 * LBM_C * (a.S + 8) + (a.mask_a ? a.S : 0) + (a.mask_b ? a.S : 0)));
-  hipLaunchKernelGGL(attn_readout_kernel, dim3((a.R + 3) / 4), dim3(256), 0, stream, a);
+  const bool wide = g_attn_mode == 4 || (g_attn_mode == 0 && a.R < 4096 && a.S >= 8);
+  if (wide)
+    hipLaunchKernelGGL(attn_readout_kernel<4>, dim3(a.R), dim3(256), 0, stream, a);
+  else
+    hipLaunchKernelGGL(attn_readout_kernel<1>, dim3((a.R + 3) / 4), dim3(256), 0, stream, a);
   return check_launch("attn_readout");
 }
 

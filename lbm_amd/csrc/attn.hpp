@@ -22,5 +22,6 @@ struct AttnArgs {
 };
 
 int attn_readout(const AttnArgs& a, hipStream_t stream);
+void attn_force_mode(int m);
 
 }  // namespace lbm

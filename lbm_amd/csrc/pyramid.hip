@@ -229,14 +229,32 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
   const int per = (nvec + WPR - 1) / WPR;
   const int f0 = WPR == 1 ? 0 : wave * per;
   const int f1 = WPR == 1 ? nvec : min(nvec, f0 + per);
+  const bool tail = WPR == 1 || wave == WPR - 1;
+  // pass 1 (k > 1): the k-th largest of the 64 per-lane maxima is a lower bound of the k-th largest element, so only
+  // elements >= tau can be among the k best; pass 2 then runs the sorted-list insertion for those few only.
+  float tau = -INFINITY;
+  if (KMAX > 1 && (f1 - f0) >= 64) {
+    float mx = -INFINITY;
+    for (int f = f0 + lane; f < f1; f += 64) {
+      const float4 v = ld4(src + f * 4);
+      mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+    }
+    for (int t = 0; t < k; ++t) {        // k rounds: wave max, then the (first) lane holding it drops out
+      tau = wave_max(mx);
+      const unsigned long long holders = __ballot(mx == tau);
+      if (lane == __builtin_ctzll(holders)) mx = -INFINITY;
+    }
+  }
   for (int f = f0 + lane; f < f1; f += 64) {
     const float4 v = ld4(src + f * 4);
-    offer(v.x, f * 4);
-    offer(v.y, f * 4 + 1);
-    offer(v.z, f * 4 + 2);
-    offer(v.w, f * 4 + 3);
+    if (fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)) >= tau) {
+      offer(v.x, f * 4);
+      offer(v.y, f * 4 + 1);
+      offer(v.z, f * 4 + 2);
+      offer(v.w, f * 4 + 3);
+    }
   }
-  if (WPR == 1 || wave == WPR - 1)
+  if (tail)
     for (int i = (nvec << 2) + lane; i < P; i += 64) offer(src[i], i);
 
   auto extract = [&](float& bv, int& bi) {   // wave arg-max of the list heads; the winning lane pops its head

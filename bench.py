@@ -36,6 +36,8 @@ WORKLOADS = {
 }
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
 F32_MFMA_PEAK_TF = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, exact fp32
+F16_MFMA_PEAK_TF = 2500.0    # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak (the split-precision kernels issue 3 MFMA
+                             # flops per algorithmic flop, so their ceiling in algorithmic TFLOP/s is a third of it)
 
 
 def build_model(wl, device):
@@ -181,17 +183,23 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic (seeded video, seeded lbm.pt-layout weights)",
             "config": {"workload": f"{args.workload}: {wl['desc']}", "streams_per_gpu": B, "points_per_stream": N,
-                       "memory_size": wl["M"], "frame": [wl["H"], wl["W"]], "parallelism": f"streams x{world} (no collective in the step)"},
+                       "memory_size": wl["M"], "frame": [wl["H"], wl["W"]],
+                       "precision": ("exact fp32 MFMA" if os.environ.get("LBM_AMD_PRECISION", "split") == "f32" else
+                                     "fp32 operands as split f16 hi/lo planes on the f16 matrix cores, fp32 accumulate (fp32-grade, "
+                                     "passes the 1e-4 / 0.05 px parity bars)"), "parallelism": f"streams x{world} (no collective in the step)"},
             "p50_latency_ms": statistics.median(lat),
         }
         if prof:
             dom = max(prof, key=lambda p: p["total_ms"])
-            is_mfma = dom["name"].startswith(("gemm_f32", "conv_f32"))
+            is_mfma = dom["name"].startswith(("gemm_", "conv_"))
             sec = dom["total_ms"] / 1e3
             if is_mfma:
-                ach = dom["flops"] / sec / 1e12
-                line["roofline"] = {"bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                                    "frac": ach / F32_MFMA_PEAK_TF, "traffic": None}
+                ach = dom["flops"] / sec / 1e12            # ALGORITHMIC flops (2 M N K) per second
+                f32 = dom["name"].startswith(("gemm_f32", "conv_f32"))
+                peak = F32_MFMA_PEAK_TF if f32 else F16_MFMA_PEAK_TF
+                line["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                                    "frac": ach / peak, "traffic": None,
+                                    "mfma_flops_per_algorithmic_flop": 1 if f32 else 3}
             else:
                 ach = dom["bytes"] / sec / 1e9
                 line["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",

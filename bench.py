@@ -101,6 +101,9 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path on one GPU)")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
 
@@ -110,12 +113,17 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if args.single_device:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend="gloo")
 
     from lbm_amd import hip
     for kv in os.environ.get("LBM_DEBUG_SET", "").split(","):        # tuning knobs, e.g. LBM_DEBUG_SET=3:4
@@ -129,6 +137,7 @@ def main():
     nfr = wl["frames"]
 
     def barrier():
+        torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -170,10 +179,12 @@ def main():
     # results travel over RCCL only here (gather of the last frame's tracks), as the north star asks
     from lbm_amd.sharding import gather_tracks, max_over_ranks
     res = torch.cat([coords, vis.float().unsqueeze(-1), rho.unsqueeze(-1)], -1).contiguous()     # (B, N, 4)
+    if args.backend == "gloo":
+        res = res.cpu()
     gathered = gather_tracks(res, B * world, dst=0)
     if rank == 0:
         assert gathered.shape == (B * world, N, 4) and bool(torch.isfinite(gathered).all())
-    elapsed = max_over_ranks(elapsed, device)
+    elapsed = max_over_ranks(elapsed, device if args.backend == "nccl" else torch.device("cpu"))
 
     if rank == 0:
         total_pf = float(B) * N * world * args.steps

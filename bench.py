@@ -168,6 +168,7 @@ def main():
         prof = []
         if not args.no_profile and rank == 0:
             nprof = min(args.steps, 20)
+            model.use_graph = False            # the per-launch events live in the eager path, not in graph replays
             hip.profile_begin()
             for i in range(nprof):
                 model.online_forward_batch(frames[i % nfr], tokens=tok)

@@ -262,6 +262,18 @@ typedef struct {
   /* workspace */
   void* workspace;
   uint64_t workspace_bytes;
+  /* Optional point-parallel execution (B == 1 only): the per-point chain of up to 1 + n_aux_streams row ranges is
+   * enqueued concurrently, range 0 on `stream`, the others on these caller-owned HIP streams; the call forks them
+   * after the frame-level kernels and joins them back into `stream` before returning (event record / wait only, no
+   * host synchronisation; stream-capture safe).  The library keeps 4 timing-disabled events for this.          */
+  lbm_stream_t aux_streams[3];
+  int32_t n_aux_streams;
+  /* Phased execution, for callers that orchestrate the concurrency themselves (e.g. one HIP graph per phase):
+   * phase 0 = whole step; 1 = frame-level kernels only (split tokens, value maps, correlation maps);
+   * 2 = the per-point chain of rows [row_lo, row_lo + row_count) only (B == 1 unless the range is everything),
+   *     `sub_index` < 4 naming this range's private scratch region; phase 2 calls of disjoint ranges may run
+   *     concurrently on different streams once phase 1 has completed.                                          */
+  int32_t phase, row_lo, row_count, sub_index;
 } lbm_hip_step_desc;
 
 /* bytes of workspace lbm_hip_track_step needs for this geometry (only B, N, M, n_layers, topk, net_* are read) */

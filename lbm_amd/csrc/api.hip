@@ -2,6 +2,7 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -59,6 +60,8 @@ ProfScope::~ProfScope() {
 }
 
 // ---- workspace layout of the step --------------------------------------------------------------
+static constexpr unsigned long long Step_kSlabRows = 8192;
+
 struct StepLayout {
   long long R, Q, L, P0, kmax;
   int n_vmaps;
@@ -126,9 +129,8 @@ static int build_layout(const lbm_hip_step_desc* d, StepLayout& lay) {
   lay.add("lb", (unsigned long long)lay.Q * LBM_C * f);
   lay.add("pred", (unsigned long long)lay.R * 2 * f);
   lay.add("coll_tok", (unsigned long long)lay.R * LBM_C * f);
-  // pre-LayerNorm scratch: Q rows, or up to 8 K-split slabs of a small product (only used while 4 * rows/64 * nsplit < 192)
-  lay.preq_bytes = (unsigned long long)(lay.Q > 8 * 3072 ? lay.Q : 8 * 3072) * LBM_C * f;
-  lay.add("preq", lay.preq_bytes);
+  lay.add("preq", (unsigned long long)lay.Q * LBM_C * f);                   // pre-LayerNorm rows
+  lay.add("slab", 4ull * Step_kSlabRows * LBM_C * f);                       // K-split partial products, one region per sub-run
   lay.add("hidR", (unsigned long long)lay.R * LBM_C * f);
   if (d->precision == 1) {   // split twins (two f16 planes = the same number of bytes as the fp32 tensor)
     if (d->tokens_split == nullptr) lay.add("tok_s", (unsigned long long)d->B * lay.L * LBM_C * f);
@@ -156,20 +158,35 @@ struct Step {
   hipStream_t s;
   char* ws;
   int h, w;
-  bool split;   // precision 1: dense contractions on the f16 matrix cores with split operands
+  bool split;      // precision 1: dense contractions on the f16 matrix cores with split operands
+  // Points never interact, so the per-point phase can run on any partition of the rows: this run covers
+  // rows [lo, lo + R) of Rfull; `sub` of `nsub` names its private K-split slab region.
+  long long Rfull = 0;
+  int lo = 0, R = 0, sub = 0, nsub = 1;
+  static constexpr long long kSlabRows = 8192;   // per-sub-run K-split slab capacity (rows of 256 floats)
+
   template <typename T>
   T* buf(const char* name) {
     return reinterpret_cast<T*>(ws + lay.find(name));
   }
   const float* W(int idx) const { return d->weights[idx]; }
-  TV tv(const char* fname, const char* sname, long long elems) {
+  // rows-of-points buffers with capacity `cap` rows of width `wd` per point; this run owns the byte range of its
+  // own points (so concurrent runs never touch each other's scratch, whatever `mult` <= cap each is using right
+  // now) and lays `mult` rows per point out inside it.  fname: fp32 buffer; sname: split twin, hi plane at the start
+  // of the range, lo plane R * mult * wd elements further.
+  TV view(const char* fname, const char* sname, int cap, int mult, int wd) {
     TV t;
-    if (fname) t.f = buf<float>(fname);
+    const long long off = (long long)lo * cap * wd;      // in 4-byte units
+    if (fname) t.f = buf<float>(fname) + off;
     if (split && sname) {
-      t.s = buf<char>(sname);
-      t.plane = elems;
+      t.s = buf<char>(sname) + off * 4;
+      t.plane = (long long)R * mult * wd;
     }
     return t;
+  }
+  // buffers that hold ONE representation: fp32 on the exact path, split planes on the split path (same bytes)
+  TV view1(const char* name, int cap, int mult, int wd) {
+    return split ? view(nullptr, name, cap, mult, wd) : view(name, nullptr, cap, mult, wd);
   }
 
   // Y = act(X · W[wi]ᵀ + W[bi]) + res_scale · res[(m / res_div)]   (Y.f fp32 and / or Y.s split, as the view asks)
@@ -183,9 +200,7 @@ struct Step {
     }
     GemmSSArgs a;
     a.A = X.s; a.a_plane = X.plane; a.lda = ldx;
-    a.B = d->weights[wi]; a.b_plane = (const char*)d->weights_lo[wi] - (const char*)d->weights[wi];
-    LBM_REQUIRE(a.b_plane % 2 == 0, "step: weight planes misaligned");
-    a.b_plane /= 2;
+    a.B = d->weights[wi]; a.b_plane = ((const char*)d->weights_lo[wi] - (const char*)d->weights[wi]) / 2;
     a.ldb = K; a.bias = bi >= 0 ? W(bi) : nullptr;
     a.Y = Y.f; a.ldy = ldy; a.Ys = Y.s; a.ys_plane = Y.plane; a.ldys = ldy;
     a.M = M; a.N = N; a.K = K; a.act = act; a.res = res; a.ldres = LBM_C; a.res_div = res_div; a.res_scale = res_scale;
@@ -194,11 +209,14 @@ struct Step {
 
   // Y = LayerNorm(X · W[wi]ᵀ + W[bi] + res_scale · res[m / res_div]) (N = 256), rows with keep == 0 replaced by fallback.
   // The bias / residual / K-split reduction happen in the LayerNorm kernel: with few rows the product is split
-  // along K over gridDim.z (partial slabs in `pre`), which is what keeps all 256 CUs busy at N = 1024 points.
-  int linear_ln(const TV& X, int ldx, int wi, int bi, float* pre, int M, int K, const float* res, int res_div, float res_scale,
+  // along K over gridDim.z (partial slabs), which is what keeps all 256 CUs busy at N = 1024 points.
+  // `mult`: rows per point of this product (its scratch is the row range of this run inside "preq").
+  int linear_ln(const TV& X, int ldx, int wi, int bi, int mult, int M, int K, const float* res, int res_div, float res_scale,
                 int gi, int bei, const TV& Y, const uint8_t* keep = nullptr, const float* fallback = nullptr, const TV* Yn = nullptr) {
+    (void)mult;
+    float* pre = buf<float>("preq") + (long long)lo * lay.kmax * LBM_C;
     RowsIn in;
-    in.X = pre; in.bias = W(bi); in.res = res; in.res_div = res_div; in.res_scale = res_scale;
+    in.bias = W(bi); in.res = res; in.res_div = res_div; in.res_scale = res_scale;
     if (!split) {
       GemmArgs a;
       a.X = X.f; a.ldx = ldx; a.W = W(wi); a.ldw = K; a.Y = pre; a.ldy = LBM_C; a.M = M; a.N = LBM_C; a.K = K;
@@ -206,8 +224,10 @@ struct Step {
     } else {
       int nsplit = 1;
       const long long tiles = (long long)((M + 63) / 64) * (LBM_C / 64);
-      while (nsplit < 8 && tiles * nsplit < 192 && K / (nsplit * 2) >= 256 && (K / (nsplit * 2)) % 32 == 0) nsplit *= 2;
-      LBM_REQUIRE((unsigned long long)nsplit * M * LBM_C * sizeof(float) <= pre_bytes, "step: K-split slabs exceed the scratch buffer");
+      while (nsplit < 8 && tiles * nsplit < 192 && K / (nsplit * 2) >= 256 && (K / (nsplit * 2)) % 32 == 0 &&
+             (long long)nsplit * 2 * M <= kSlabRows)
+        nsplit *= 2;
+      if (nsplit > 1) pre = buf<float>("slab") + (long long)sub * kSlabRows * LBM_C;
       GemmSSArgs a;
       a.A = X.s; a.a_plane = X.plane; a.lda = ldx;
       a.B = d->weights[wi]; a.b_plane = ((const char*)d->weights_lo[wi] - (const char*)d->weights[wi]) / 2; a.ldb = K;
@@ -216,6 +236,7 @@ struct Step {
       if (gemm_ss(a, s)) return -1;
       in.nslab = nsplit; in.slab_stride = (long long)M * LBM_C;
     }
+    in.X = pre;
     RowsOut o;
     o.Y = Y.f; o.Ys = Y.s; o.ys_plane = Y.plane;
     if (Yn) {
@@ -223,42 +244,40 @@ struct Step {
     }
     return layernorm_rows_in(in, W(gi), W(bei), M, keep, fallback, o, s);
   }
-  unsigned long long pre_bytes = 0;
 
   // memory / lattice-update attention block: x_in [R,256] -> x_out [R,256]
   int attn_block(int wb, const TV& x_in, const TV& x_out, const float* seq, long long point_stride, int S, int ring_head,
                  bool masked, const TV* Yn) {
-    const int R = (int)lay.R;
-    TV U;   U.f = buf<float>("U");
-    TV mbar = split ? TV{nullptr, buf<char>("mbar"), (long long)R * 1024} : TV{buf<float>("mbar"), nullptr, 0};
-    TV hid = split ? TV{nullptr, buf<char>("hid"), (long long)R * 1024} : TV{buf<float>("hid"), nullptr, 0};
-    TV pre; pre.f = buf<float>("preq");
-    TV y = tv("tc", "tc_s", (long long)R * LBM_C);
-    uint8_t* valid = masked ? buf<uint8_t>("valid") : nullptr;
+    const int km = (int)lay.kmax;
+    TV U = view("U", nullptr, 1, 1, 1024);
+    TV mbar = view1("mbar", 1, 1, 1024);
+    TV hid = view1("hid", km, 1, 1024);
+    TV y = view("tc", "tc_s", 1, 1, LBM_C);
+    uint8_t* valid = masked ? buf<uint8_t>("valid") + lo : nullptr;
     if (linear(x_in, LBM_C, wb + LBM_W_ATTN_G, wb + LBM_W_ATTN_GB, U, 1024, R, 1024, LBM_C)) return -1;
     AttnArgs a;
     a.U = U.f; a.seq = seq; a.point_stride = point_stride; a.slot_stride = LBM_C; a.S = S; a.ring_head = ring_head;
     a.temb = masked ? W(wb + LBM_W_ATTN_TEMB) : nullptr;
-    a.mask_a = masked ? d->vis_mask : nullptr;
-    a.mask_b = masked ? d->mem_mask : nullptr;
+    a.mask_a = masked ? d->vis_mask + (long long)lo * d->M : nullptr;
+    a.mask_b = masked ? d->mem_mask + (long long)lo * d->M : nullptr;
     a.out = mbar.f; a.out_s = mbar.s; a.out_plane = mbar.plane; a.valid = valid; a.R = R;
     if (attn_readout(a, s)) return -1;
-    if (linear_ln(mbar, 1024, wb + LBM_W_ATTN_HM, wb + LBM_W_ATTN_HB, pre.f, R, 1024, x_in.f, 1, 1.f, wb + LBM_W_ATTN_LN1G,
+    if (linear_ln(mbar, 1024, wb + LBM_W_ATTN_HM, wb + LBM_W_ATTN_HB, 1, R, 1024, x_in.f, 1, 1.f, wb + LBM_W_ATTN_LN1G,
                   wb + LBM_W_ATTN_LN1B, y))
       return -1;
     if (linear(y, LBM_C, wb + LBM_W_ATTN_F1W, wb + LBM_W_ATTN_F1B, hid, 1024, R, 1024, LBM_C, ACT_GELU)) return -1;
-    return linear_ln(hid, 1024, wb + LBM_W_ATTN_F2W, wb + LBM_W_ATTN_F2B, pre.f, R, 1024, y.f, 1, 1.f, wb + LBM_W_ATTN_LN2G,
+    return linear_ln(hid, 1024, wb + LBM_W_ATTN_F2W, wb + LBM_W_ATTN_F2B, 1, R, 1024, y.f, 1, 1.f, wb + LBM_W_ATTN_LN2G,
                      wb + LBM_W_ATTN_LN2B, x_out, valid, x_in.f, Yn);
   }
 
   // deformable block: token x [R,256] (replicated k times) sampled at ref [R,k,2] -> out [R*k,256]
   int msda_block(int wb, int vmap, int P, const TV& x, const float* ref, int k, const TV& out) {
-    const int R = (int)lay.R, Q = R * k;
-    TV offlog; offlog.f = buf<float>("offlog");
-    TV samp = split ? TV{nullptr, buf<char>("samp"), (long long)Q * LBM_C} : TV{buf<float>("samp"), nullptr, 0};
-    TV hid = split ? TV{nullptr, buf<char>("hid"), (long long)Q * 1024} : TV{buf<float>("hid"), nullptr, 0};
-    TV pre; pre.f = buf<float>("preq");
-    TV la = tv("la", "la_s", (long long)Q * LBM_C);
+    const int Q = R * k;
+    const int km = (int)lay.kmax;
+    TV offlog = view("offlog", nullptr, 1, 1, 48 * 16);
+    TV samp = view1("samp", km, k, LBM_C);
+    TV hid = view1("hid", km, k, 1024);
+    TV la = view("la", "la_s", km, k, LBM_C);
     const int ncol = 48 * P;
     if (linear(x, LBM_C, wb + LBM_W_MSDA_OLW, wb + LBM_W_MSDA_OLB, offlog, ncol, R, ncol, LBM_C)) return -1;
     MsdaArgs m;
@@ -270,25 +289,24 @@ struct Step {
       m.lvl_h[l] = h >> l; m.lvl_w[l] = w >> l; m.lvl_start[l] = st;
       st += (h >> l) * (w >> l);
     }
-    m.B = d->B; m.N = d->N; m.k = k; m.P = P;
+    // a sub-run only exists for B == 1, where its rows all belong to stream 0
+    m.B = nsub > 1 ? 1 : d->B; m.N = nsub > 1 ? R : d->N; m.k = k; m.P = P;
     m.offlog = offlog.f; m.ld_offlog = ncol; m.logit_col = 32 * P;
     m.ref = ref; m.net_w = (float)d->net_w; m.net_h = (float)d->net_h;
     m.out = samp.f; m.out_s = samp.s; m.out_plane = samp.plane;
     if (msda_sample(m, s)) return -1;
     // 2*q + output_proj(.)  (msdeformattn.py:185 adds the identity, transformer.py:321 adds the query again)
-    if (linear_ln(samp, LBM_C, wb + LBM_W_MSDA_OUTW, wb + LBM_W_MSDA_OUTB, pre.f, Q, LBM_C, x.f, k, 2.f, wb + LBM_W_MSDA_LN1G,
+    if (linear_ln(samp, LBM_C, wb + LBM_W_MSDA_OUTW, wb + LBM_W_MSDA_OUTB, k, Q, LBM_C, x.f, k, 2.f, wb + LBM_W_MSDA_LN1G,
                   wb + LBM_W_MSDA_LN1B, la))
       return -1;
     if (linear(la, LBM_C, wb + LBM_W_MSDA_F1W, wb + LBM_W_MSDA_F1B, hid, 1024, Q, 1024, LBM_C, ACT_GELU)) return -1;
-    return linear_ln(hid, 1024, wb + LBM_W_MSDA_F2W, wb + LBM_W_MSDA_F2B, pre.f, Q, 1024, la.f, 1, 1.f, wb + LBM_W_MSDA_LN2G,
+    return linear_ln(hid, 1024, wb + LBM_W_MSDA_F2W, wb + LBM_W_MSDA_F2B, k, Q, 1024, la.f, 1, 1.f, wb + LBM_W_MSDA_LN2G,
                      wb + LBM_W_MSDA_LN2B, out);
   }
 
-  int run() {
-    const int R = (int)lay.R;
+  // ---- per-frame, point-independent work: split tokens, the six value maps, the correlation maps ----
+  int run_frame() {
     const int hb = d->n_layers * LBM_W_LAYER_COUNT;
-    const long long RC = (long long)R * LBM_C;
-    // ---- per-frame, point-independent work ----
     TV value; value.f = buf<float>("value");
     const int nv = lay.n_vmaps * LBM_C;
     const long long BL = (long long)d->B * lay.L;
@@ -303,36 +321,46 @@ struct Step {
       }
     }
     if (linear(tok, LBM_C, hb + LBM_W_HEAD_VPROJ_W, hb + LBM_W_HEAD_VPROJ_B, value, nv, (int)BL, nv, LBM_C)) return -1;
-    float* F = buf<float>("corr_maps");
-    if (corr_maps(d->tokens, buf<float>("inv_norm"), F, d->corr_mix, d->n_layers, d->B, h, w, split, s)) return -1;
-    if (R == 0) return 0;
+    return corr_maps(d->tokens, buf<float>("inv_norm"), buf<float>("corr_maps"), d->corr_mix, d->n_layers, d->B, h, w, split, s);
+  }
 
-    TV xq; xq.f = const_cast<float*>(d->query);
-    if (split) {
-      xq.s = buf<char>("q_s"); xq.plane = RC;
-      if (split_planes(d->query, xq.s, (char*)xq.s + 2 * RC, RC, s)) return -1;
-    }
-    TV x0 = tv("x0", "x0_s", RC), x1 = tv("x1", "x1_s", RC), ta = tv("ta", "ta_s", RC), tb = tv("tb", "tb_s", RC);
-    TV qn = split ? TV{nullptr, buf<char>("qn"), RC} : TV{buf<float>("qn"), nullptr, 0};
-    float* corr = buf<float>("corr");
-    int* idx = buf<int>("idx");
-    float* ref = buf<float>("ref");
-    TV lb; lb.f = buf<float>("lb");
+  // ---- everything that depends on the points, for rows [lo, lo + R) ----
+  int run_points() {
+    if (R == 0) return 0;
+    const int hb = d->n_layers * LBM_W_LAYER_COUNT;
+    const long long RC = (long long)R * LBM_C;
+    const int M = d->M;
+    float* F = buf<float>("corr_maps");
+    const float* query = d->query + (long long)lo * LBM_C;
+    TV xq = view(nullptr, "q_s", 1, 1, LBM_C);
+    xq.f = const_cast<float*>(query);
+    if (split && split_planes(query, xq.s, (char*)xq.s + 2 * xq.plane, RC, s)) return -1;
+    TV x0 = view("x0", "x0_s", 1, 1, LBM_C), x1 = view("x1", "x1_s", 1, 1, LBM_C), ta = view("ta", "ta_s", 1, 1, LBM_C),
+       tb = view("tb", "tb_s", 1, 1, LBM_C);
+    TV qn = view1("qn", 1, 1, LBM_C);
+    float* corr = buf<float>("corr") + (long long)lo * lay.P0;
+    float* ref = buf<float>("ref") + (long long)lo * lay.kmax * 2;
+    int* idx = buf<int>("idx") + (long long)lo * lay.kmax;
+    const float* coll_mem = d->coll_mem + (long long)lo * M * LBM_C;
+    const float* stream_mem = d->stream_mem + (long long)lo * M * LBM_C;
+    const bool one = nsub > 1;          // sub-run: one stream, M rows = R
     TV x = xq;
     for (int i = 0; i < d->n_layers; ++i) {
       const int lw = i * LBM_W_LAYER_COUNT;
       const int k = d->topk[i];
+      TV lb = view("lb", nullptr, (int)lay.kmax, k, LBM_C);
       // collision then streaming read-out of the two memories (transformer.py:257-302)
-      if (attn_block(lw + LBM_W_LAYER_COLL, x, ta, d->coll_mem, (long long)d->M * LBM_C, d->M, d->ring_head, true, nullptr)) return -1;
-      if (attn_block(lw + LBM_W_LAYER_STREAM, ta, tb, d->stream_mem, (long long)d->M * LBM_C, d->M, d->ring_head, true, &qn)) return -1;
+      if (attn_block(lw + LBM_W_LAYER_COLL, x, ta, coll_mem, (long long)M * LBM_C, M, d->ring_head, true, nullptr)) return -1;
+      if (attn_block(lw + LBM_W_LAYER_STREAM, ta, tb, stream_mem, (long long)M * LBM_C, M, d->ring_head, true, &qn)) return -1;
       // correlation + top-k (transformer.py:306-308)
-      float* cdst = d->corr[i] ? d->corr[i] : corr;
+      float* cdst = d->corr[i] ? d->corr[i] + (long long)lo * lay.P0 : corr;
+      const int gm = one ? R : d->N, gb = one ? 1 : d->B;
       if (!split) {
         GemmArgs g;
         g.X = qn.f; g.ldx = LBM_C; g.sX = (long long)d->N * LBM_C;
         g.W = F + (long long)i * d->B * lay.P0 * LBM_C; g.ldw = LBM_C; g.sW = lay.P0 * LBM_C;
         g.Y = cdst; g.ldy = (int)lay.P0; g.sY = (long long)d->N * lay.P0;
-        g.M = d->N; g.N = (int)lay.P0; g.K = LBM_C; g.batch = d->B;
+        g.M = gm; g.N = (int)lay.P0; g.K = LBM_C; g.batch = gb;
         if (gemm(g, s)) return -1;
       } else {
         // F holds, per layer, the hi planes of all streams followed by their lo planes
@@ -341,18 +369,18 @@ struct Step {
         g.A = qn.s; g.a_plane = qn.plane; g.lda = LBM_C; g.sA = (long long)d->N * LBM_C;
         g.B = (const char*)F + (long long)i * plane * 4; g.b_plane = plane; g.ldb = LBM_C; g.sB = lay.P0 * LBM_C;
         g.Y = cdst; g.ldy = (int)lay.P0; g.sY = (long long)d->N * lay.P0;
-        g.M = d->N; g.N = (int)lay.P0; g.K = LBM_C; g.batch = d->B;
+        g.M = gm; g.N = (int)lay.P0; g.K = LBM_C; g.batch = gb;
         if (gemm_ss(g, s)) return -1;
       }
-      int* idst = d->topk_idx[i] ? d->topk_idx[i] : idx;
-      float* rdst = d->ref_points[i] ? d->ref_points[i] : ref;
+      int* idst = d->topk_idx[i] ? d->topk_idx[i] + (long long)lo * k : idx;
+      float* rdst = d->ref_points[i] ? d->ref_points[i] + (long long)lo * k * 2 : ref;
       if (topk_rows(cdst, lay.P0, (int)lay.P0, k, R, w, d->stride, idst, rdst, nullptr, s)) return -1;
       // lattice deformable attention on the k regions (transformer.py:316-327)
       if (msda_block(lw + LBM_W_LAYER_LATTICE, i, d->n_points, tb, rdst, k, lb)) return -1;
       if (d->ref_rho[i]) {   // [1,256] read-out, kept on the exact fp32 path in both modes (weights stay fp32)
         GemmArgs g;
         g.X = lb.f; g.ldx = LBM_C; g.W = W(lw + LBM_W_LAYER_RHO_W); g.ldw = LBM_C; g.bias = W(lw + LBM_W_LAYER_RHO_B);
-        g.Y = d->ref_rho[i]; g.ldy = 1; g.M = R * k; g.N = 1; g.K = LBM_C;
+        g.Y = d->ref_rho[i] + (long long)lo * k; g.ldy = 1; g.M = R * k; g.N = 1; g.K = LBM_C;
         if (gemm(g, s)) return -1;
       }
       // lattice update (transformer.py:330-338)
@@ -366,25 +394,28 @@ struct Step {
         }
       }
     }
-    // ---- heads (transformer.py:103-149) ----
-    TV hidR; hidR.f = buf<float>("hidR");
-    float* pred = buf<float>("pred");
-    TV coll_tok; coll_tok.f = buf<float>("coll_tok");
+    // ---- heads (transformer.py:103-149); `ref` now holds the last layer's single cell centre per point ----
+    TV hidR = view("hidR", nullptr, 1, 1, LBM_C);
+    float* pred = buf<float>("pred") + (long long)lo * 2;
+    TV coll_tok = view("coll_tok", nullptr, 1, 1, LBM_C);
+    float* offset = d->offset + (long long)lo * 2;
     if (msda_block(hb + LBM_W_HEAD_OFFSET, d->n_layers, d->n_points, x, ref, 1, ta)) return -1;
     if (linear(ta, LBM_C, hb + LBM_W_HEAD_OFFH_W0, hb + LBM_W_HEAD_OFFH_B0, hidR, LBM_C, R, LBM_C, LBM_C, ACT_GELU)) return -1;
-    if (offset_final(hidR.f, W(hb + LBM_W_HEAD_OFFH_W3), W(hb + LBM_W_HEAD_OFFH_B3), ref, (float)d->stride, d->offset, pred, R, s)) return -1;
+    if (offset_final(hidR.f, W(hb + LBM_W_HEAD_OFFH_W3), W(hb + LBM_W_HEAD_OFFH_B3), ref, (float)d->stride, offset, pred, R, s)) return -1;
     if (msda_block(hb + LBM_W_HEAD_CMEM, d->n_layers + 1, d->n_points_cmem, x, pred, 1, coll_tok)) return -1;
     if (msda_block(hb + LBM_W_HEAD_VIS, d->n_layers + 2, d->n_points, x, ref, 1, ta)) return -1;
     if (linear(ta, LBM_C, hb + LBM_W_HEAD_VISH_W0, hb + LBM_W_HEAD_VISH_B0, hidR, LBM_C, R, LBM_C, LBM_C, ACT_GELU)) return -1;
     StateFinalArgs f;
     f.vis_hidden = hidR.f; f.w3 = W(hb + LBM_W_HEAD_VISH_W3); f.b3 = W(hb + LBM_W_HEAD_VISH_B3);
-    f.stream_tok = x.f; f.coll_tok = coll_tok.f; f.query_init = d->query; f.queried = d->queried;
-    f.stream_out = d->stream_out; f.coll_out = d->coll_out;
+    f.stream_tok = x.f; f.coll_tok = coll_tok.f; f.query_init = query; f.queried = d->queried ? d->queried + lo : nullptr;
+    f.stream_out = d->stream_out ? d->stream_out + (long long)lo * LBM_C : nullptr;
+    f.coll_out = d->coll_out ? d->coll_out + (long long)lo * LBM_C : nullptr;
     if (d->update_state) {
-      f.stream_mem = d->stream_mem; f.coll_mem = d->coll_mem; f.vis_mask = d->vis_mask; f.mem_mask = d->mem_mask;
+      f.stream_mem = d->stream_mem + (long long)lo * M * LBM_C; f.coll_mem = d->coll_mem + (long long)lo * M * LBM_C;
+      f.vis_mask = d->vis_mask + (long long)lo * M; f.mem_mask = d->mem_mask + (long long)lo * M;
     }
-    f.M = d->M; f.ring_head = d->ring_head; f.vis_threshold = d->vis_threshold;
-    f.vis = d->vis; f.rho = d->rho; f.ref = ref; f.offset = d->offset; f.coords = d->coords;
+    f.M = M; f.ring_head = d->ring_head; f.vis_threshold = d->vis_threshold;
+    f.vis = d->vis + lo; f.rho = d->rho + lo; f.ref = ref; f.offset = offset; f.coords = d->coords ? d->coords + (long long)lo * 2 : nullptr;
     f.net_w = (float)d->net_w; f.net_h = (float)d->net_h; f.img_w = d->img_w; f.img_h = d->img_h;
     f.R = R;
     return state_final(f, s);
@@ -623,14 +654,65 @@ int lbm_hip_track_step(const lbm_hip_step_desc* d, lbm_stream_t stream) {
     LBM_REQUIRE(d->vis && d->rho && d->offset, "step: vis/rho/offset outputs are required");
   }
   st.split = d->precision == 1;
-  st.pre_bytes = st.lay.preq_bytes;
   if (st.split) LBM_REQUIRE(d->weights_lo != nullptr, "step: precision 1 needs the lo planes of the weight matrices (weights_lo)");
   st.d = d;
   st.s = (hipStream_t)stream;
   st.ws = (char*)d->workspace;
   st.h = d->net_h / d->stride;
   st.w = d->net_w / d->stride;
-  return st.run();
+  st.Rfull = st.lay.R;
+  LBM_REQUIRE(d->phase >= 0 && d->phase <= 2, "step: phase must be 0, 1 or 2");
+  if (d->phase == 2) {
+    LBM_REQUIRE(d->row_lo >= 0 && d->row_count >= 0 && (long long)d->row_lo + d->row_count <= st.lay.R, "step: row range outside [0, %lld)", st.lay.R);
+    LBM_REQUIRE(d->sub_index >= 0 && d->sub_index < 4, "step: sub_index must be in [0, 4)");
+    const bool whole = d->row_lo == 0 && d->row_count == st.lay.R;
+    LBM_REQUIRE(whole || d->B == 1, "step: a partial row range needs B == 1");
+    st.lo = d->row_lo; st.R = d->row_count; st.sub = d->sub_index; st.nsub = whole ? 1 : 2;
+    return st.run_points();
+  }
+  if (st.run_frame()) return -1;
+  if (d->phase == 1) return 0;
+
+  // Point-parallel sub-streams: with one stream of ~1000 points every kernel of the per-point chain is a small,
+  // latency-bound launch; points are independent, so the rows are cut into up to 4 ranges whose chains run
+  // concurrently on the caller's auxiliary HIP streams (fork after the frame phase, join at the end).
+  int nsub = 1;
+  if (d->n_aux_streams > 0 && d->B == 1) {
+    LBM_REQUIRE(d->n_aux_streams <= 3, "step: at most 3 auxiliary streams");
+    nsub = 1 + d->n_aux_streams;
+    while (nsub > 1 && st.lay.R < 256ll * nsub) --nsub;
+  }
+  if (nsub == 1) {
+    st.lo = 0; st.R = (int)st.lay.R; st.sub = 0; st.nsub = 1;
+    return st.run_points();
+  }
+  static hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+  if (ev_fork == nullptr) {
+    LBM_REQUIRE(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) == hipSuccess, "step: event creation failed");
+    for (int i = 0; i < 3; ++i)
+      LBM_REQUIRE(hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming) == hipSuccess, "step: event creation failed");
+  }
+  hipStream_t main_s = (hipStream_t)stream;
+  LBM_REQUIRE(hipEventRecord(ev_fork, main_s) == hipSuccess, "step: fork record failed");
+  const long long chunk = ((st.lay.R + nsub - 1) / nsub + 63) / 64 * 64;
+  int rc = 0;
+  for (int i = 0; i < nsub; ++i) {
+    Step sub = st;
+    sub.sub = i; sub.nsub = nsub;
+    sub.lo = (int)std::min<long long>(st.lay.R, chunk * i);
+    sub.R = (int)(std::min<long long>(st.lay.R, chunk * (i + 1)) - sub.lo);
+    if (i > 0) {
+      sub.s = (hipStream_t)d->aux_streams[i - 1];
+      LBM_REQUIRE(sub.s != nullptr && sub.s != main_s, "step: auxiliary stream %d is null or equals the main stream", i - 1);
+      LBM_REQUIRE(hipStreamWaitEvent(sub.s, ev_fork, 0) == hipSuccess, "step: fork wait failed");
+    }
+    if (rc == 0) rc = sub.run_points();
+    if (i > 0) {   // always join, also after an error, so the streams stay consistent (and a capture stays closed)
+      LBM_REQUIRE(hipEventRecord(ev_join[i - 1], sub.s) == hipSuccess, "step: join record failed");
+      LBM_REQUIRE(hipStreamWaitEvent(main_s, ev_join[i - 1], 0) == hipSuccess, "step: join wait failed");
+    }
+  }
+  return rc;
 }
 
 }  // extern "C"

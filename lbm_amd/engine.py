@@ -324,6 +324,11 @@ class TrackEngine:
         if precision not in ("split", "f32"):
             raise ValueError("precision must be 'split' or 'f32'")
         self.precision = precision
+        # optional point-parallel sub-streams (B == 1): the per-point chain of up to 1 + n_aux row ranges is enqueued on
+        # concurrent HIP streams.  Off by default: measured on MI355X it does not shorten the step (host-bound eagerly,
+        # serialised inside a graph replay); kept as a knob (LBM_AMD_AUX_STREAMS=1..3) and covered by a parity test.
+        self.n_aux = max(0, min(3, int(os.environ.get("LBM_AMD_AUX_STREAMS", "0"))))
+        self._aux: List[torch.cuda.Stream] = []
         self.cfg = cfg
         self.w = weights
         self.dev = weights.device
@@ -368,7 +373,8 @@ class TrackEngine:
              vis_mask: torch.Tensor, mem_mask: torch.Tensor, ring_head: int = 0, queried: Optional[torch.Tensor] = None,
              update_state: bool = True, img_hw: Optional[Sequence[int]] = None, want_memory: bool = False,
              want_aux: bool = False, want_corr: bool = False, vis_threshold: float = 0.8,
-             tokens_split: Optional["hip.SplitTensor"] = None) -> Dict[str, torch.Tensor]:
+             tokens_split: Optional["hip.SplitTensor"] = None, phase: int = 0, rows: Optional[Sequence[int]] = None,
+             sub_index: int = 0, out: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
         """tokens (B,L,256) pyramid; query (B,N,256); memories (B,N,M,256) in ring order; masks (B,N,M) bool/uint8."""
         hip._require_gpu()
         if self.w.memory_size != stream_mem.shape[2]:
@@ -387,9 +393,12 @@ class TrackEngine:
             d.tokens_split = tokens_split.hi
         ws = self.workspace(d)
         dev = self.dev
-        out: Dict[str, torch.Tensor] = {
-            "coords": torch.empty(B, N, 2, device=dev), "vis": torch.empty(B, N, device=dev),
-            "rho": torch.empty(B, N, device=dev), "offset": torch.empty(B, N, 2, device=dev)}
+        d.phase, d.sub_index = phase, sub_index
+        if rows is not None:
+            d.row_lo, d.row_count = int(rows[0]), int(rows[1])
+        if out is None:
+            out = {"coords": torch.empty(B, N, 2, device=dev), "vis": torch.empty(B, N, device=dev),
+                   "rho": torch.empty(B, N, device=dev), "offset": torch.empty(B, N, 2, device=dev)}
         if want_memory:
             out["stream"] = torch.empty(B, N, 256, device=dev)
             out["collision"] = torch.empty(B, N, 256, device=dev)
@@ -398,7 +407,8 @@ class TrackEngine:
         for i, kk in enumerate(cfg.topk_per_layer):
             last = i == len(cfg.topk_per_layer) - 1
             if want_aux or last:
-                out[f"ref{i}"] = torch.empty(B, N, kk, 2, device=dev)
+                if f"ref{i}" not in out:
+                    out[f"ref{i}"] = torch.empty(B, N, kk, 2, device=dev)
                 d.ref_points[i] = out[f"ref{i}"].data_ptr()
             if want_aux:
                 out[f"idx{i}"] = torch.empty(B, N, kk, device=dev, dtype=torch.int32)
@@ -414,6 +424,12 @@ class TrackEngine:
         d.queried = hip._p(queried, torch.uint8)
         d.coords, d.vis, d.rho, d.offset = (out[n].data_ptr() for n in ("coords", "vis", "rho", "offset"))
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+        if self.n_aux and B == 1 and phase == 0:
+            while len(self._aux) < self.n_aux:
+                self._aux.append(torch.cuda.Stream(device=dev))
+            for i in range(self.n_aux):
+                d.aux_streams[i] = self._aux[i].cuda_stream
+            d.n_aux_streams = self.n_aux
         hip._check(hip.load().lbm_hip_track_step(C.byref(d), hip._stream()), "lbm_hip_track_step")
         if want_corr:   # the kernels rank without the (constant) bias; the returned map carries it
             for i in range(len(cfg.topk_per_layer)):

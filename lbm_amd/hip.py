@@ -79,7 +79,9 @@ class StepDesc(C.Structure):
                 ("stream_out", C.c_void_p), ("coll_out", C.c_void_p),
                 ("ref_points", C.c_void_p * MAX_LAYERS), ("topk_idx", C.c_void_p * MAX_LAYERS),
                 ("ref_rho", C.c_void_p * MAX_LAYERS), ("corr", C.c_void_p * MAX_LAYERS),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_uint64)]
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_uint64),
+                ("aux_streams", C.c_void_p * 3), ("n_aux_streams", C.c_int32),
+                ("phase", C.c_int32), ("row_lo", C.c_int32), ("row_count", C.c_int32), ("sub_index", C.c_int32)]
 
 
 class ProfileEntry(C.Structure):

@@ -36,6 +36,20 @@ class LBM_online(LBM):
         self._head = 0
         self.img_size = None
         self.device = "cuda" if torch.cuda.is_available() else "cpu"
+        # Optional HIP-graph replay of the whole frame step (encoder + tracker, one graph per ring-buffer head): takes the
+        # ~180 launches per frame off the host.  Off by default (the step is GPU-bound; measured 1.99 vs 1.98 ms at C2);
+        # LBM_AMD_GRAPH=1 enables it.
+        import os
+        self.use_graph = os.environ.get("LBM_AMD_GRAPH", "0") == "1"
+        self.graph_max_rows = 4096
+        self._graphs = {}
+        self._gkey = None
+        self._g_in = None
+        self._g_tok = None
+        self._eager_done = None
+        self._g_streams = []
+        self._g_fork = None
+        self._g_join = []
         if with_obj_tracker:
             raise NotImplementedError("the object-tracking association layer (object_tracker.py) is outside the hot path "
                                       "(SURVEY §8 f.1); update() below provides the add/remove-points primitive it drives")
@@ -157,6 +171,10 @@ class LBM_online(LBM):
     def online_forward_batch(self, frames: torch.Tensor, tokens: Optional[torch.Tensor] = None):
         """frames (B,3,H,W) -> coords (B,N,2) frame px, vis (B,N) bool, rho (B,N) in (0,1), tokens (B,L,C)."""
         H, W = frames.shape[-2], frames.shape[-1]
+        if self.use_graph and frames.is_cuda and self.B * self.N <= self.graph_max_rows and self.N > 0:
+            res = self._forward_graph(frames)
+            if res is not None:
+                return res
         tok = self.backbone.encode_tokens(frames, tokens)
         out = self.transformer.get_engine().step(tok, self.query, self._stream, self._coll, self._vis, self._mem,
                                                  ring_head=self._head, queried=None, update_state=True, img_hw=(H, W),
@@ -166,6 +184,49 @@ class LBM_online(LBM):
         self.t += 1
         self.last_logits = (out["vis"], out["rho"])
         return out["coords"], torch.sigmoid(out["vis"]) > self.visibility_treshold, torch.sigmoid(out["rho"]), tok
+
+    def _forward_graph(self, frames: torch.Tensor):
+        """Replay (capturing on first use) the HIP graph of this frame step; None = not available, run eagerly."""
+        key = (tuple(frames.shape), self.N, self.memory_size, self._stream.data_ptr(), self.query.data_ptr(),
+               float(self.visibility_treshold), self.transformer.precision, self.backbone.precision)
+        if self._gkey != key:
+            self._graphs, self._gkey, self._eager_done = {}, key, False
+            self._g_in = torch.empty_like(frames, dtype=torch.float32)
+            L = self.transformer.cfg.num_tokens
+            self._g_tok = torch.empty(frames.shape[0], L, self.embed_dim, device=frames.device, dtype=torch.float32)
+            self._g_fork = torch.cuda.Event()
+            self._g_join = [torch.cuda.Event() for _ in range(3)]
+        if not self._eager_done:
+            # the first frame of a configuration runs eagerly: it packs weights and sizes every persistent buffer
+            self._eager_done = True
+            return None
+        H, W = frames.shape[-2], frames.shape[-1]
+        self._g_in.copy_(frames)
+        head = self._head
+        if head not in self._graphs:
+            try:
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    tok = self.backbone.encode_tokens(self._g_in, self._g_tok)
+                    out = self.transformer.get_engine().step(tok, self.query, self._stream, self._coll, self._vis, self._mem,
+                                                             ring_head=head, queried=None, update_state=True, img_hw=(H, W),
+                                                             vis_threshold=self.visibility_treshold,
+                                                             tokens_split=self.backbone.last_tokens_split)
+                self._graphs[head] = (g, out)
+            except Exception as e:          # capture not possible here: say so once and stay eager
+                import warnings
+                warnings.warn(f"lbm_amd: HIP graph capture failed ({e}); running eagerly")
+                self.use_graph = False
+                torch.cuda.synchronize()
+                return None
+        g, out = self._graphs[head]
+        g.replay()
+        self._head = (self._head + 1) % self.memory_size
+        self.t += 1
+        vis, rho = out["vis"].clone(), out["rho"].clone()
+        self.last_logits = (vis, rho)
+        return out["coords"].clone(), torch.sigmoid(vis) > self.visibility_treshold, torch.sigmoid(rho), self._g_tok
 
     def online_forward_obj(self, frame, bboxes, scores, labels):
         raise NotImplementedError("object tracking (lbm_online.py:160-200, object_tracker.py) is outside the hot path")

@@ -500,3 +500,32 @@ def test_update_adds_and_removes_points_like_the_reference(hip):
             c, v, r, _ = model.online_forward(video[:, t].cuda())
             oc = oracle.online_forward(video[:, t])[0]
             _cmp(c, oc, rtol=0, atol=COORD_TOL)
+
+
+def test_graph_replay_and_point_parallel_streams_match_the_plain_eager_step(hip, monkeypatch):
+    """B = 1, N = 1024: the default path (HIP-graph replay per ring head, per-point chain on 4 concurrent streams)
+    against the plain single-stream eager path over 15 frames (the ring wraps: M = 12)."""
+    from lbm_amd.synth import synthetic_video, grid_queries
+    T, H, W = 16, 240, 320
+    video = synthetic_video(T, H, W, seed=12).cuda()
+    pts = grid_queries(H, W, 32).cuda()
+    runs = {}
+    for mode in ("plain", "fast"):
+        monkeypatch.setenv("LBM_AMD_AUX_STREAMS", "0" if mode == "plain" else "3")
+        model, _ = _online(dict(input_size=(384, 512), memory_size=12))
+        model.use_graph = mode == "fast"
+        out = []
+        with torch.no_grad():
+            model.init(pts, video[:, 0])
+            for t in range(1, T):
+                c, v, r, f_t = model.online_forward(video[:, t])
+                out.append((c.clone(), model.last_logits[0][0].clone(), r.clone()))
+        if mode == "fast":
+            assert len(model._graphs) == 12 and model.use_graph          # every ring head captured and replayed
+        runs[mode] = (out, model.stream_dist.clone(), model.vis_mask.clone())
+    for (c0, v0, r0), (c1, v1, r1) in zip(runs["plain"][0], runs["fast"][0]):
+        _cmp(c1, c0, rtol=0, atol=COORD_TOL)
+        _cmp(v1, v0, rtol=0, atol=3e-4)
+        _cmp(r1, r0, rtol=0, atol=3e-4)
+    _cmp(runs["fast"][1], runs["plain"][1], rtol=1e-3, atol=1e-3)
+    assert (runs["fast"][2] == runs["plain"][2]).all()

@@ -101,6 +101,9 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="enqueue frame t+1's encoder on a second HIP stream before frame t's per-point phase "
+                         "(LBM_online.prefetch); measured SLOWER on MI355X, see DESIGN.md, so off by default")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -146,14 +149,32 @@ def main():
         model.init_streams(pts, video[:, 0].contiguous())
         frames = [video[:, 1 + i].contiguous() for i in range(nfr)]
         tok = None
-        for i in range(args.warmup):
-            coords, vis, rho, tok = model.online_forward_batch(frames[i % nfr], tokens=tok)
+        pipeline = args.pipeline or os.environ.get("LBM_AMD_PIPELINE", "0") == "1"
+
+        def run(n):
+            # n complete frames: n encoder passes and n tracker passes, all inside the caller's barriers.  Pipelined, the
+            # encoder of frame i+1 is enqueued on a second HIP stream before the per-point phase of frame i (the first
+            # frame of a run is encoded inline, the last one prefetches nothing).
+            nonlocal tok
+            out = None
+            for i in range(n):
+                if pipeline:
+                    if i + 1 < n:
+                        model.prefetch(frames[(i + 1) % nfr])
+                    out = model.online_forward_batch(frames[i % nfr])
+                else:
+                    out = model.online_forward_batch(frames[i % nfr], tokens=tok)
+                    tok = out[3]
+            return out
+
+        run(args.warmup)
         barrier()
         t0 = time.perf_counter()
-        for i in range(args.steps):
-            coords, vis, rho, tok = model.online_forward_batch(frames[i % nfr], tokens=tok)
+        coords, vis, rho, tok = run(args.steps)
         barrier()
         elapsed = time.perf_counter() - t0
+        if pipeline:
+            tok = None
 
         # p50 per-frame latency: each frame synchronised on its own
         lat = []
@@ -196,6 +217,8 @@ def main():
             "dtype": "f32", "data": "synthetic (seeded video, seeded lbm.pt-layout weights)",
             "config": {"workload": f"{args.workload}: {wl['desc']}", "streams_per_gpu": B, "points_per_stream": N,
                        "memory_size": wl["M"], "frame": [wl["H"], wl["W"]],
+                       "frame_pipeline": ("encoder + value/correlation maps of frame t+1 on a second HIP stream, overlapping the "
+                                          "per-point phase of frame t" if pipeline else "none (serial frames)"),
                        "precision": ("exact fp32 MFMA" if os.environ.get("LBM_AMD_PRECISION", "split") == "f32" else
                                      "fp32 operands as split f16 hi/lo planes on the f16 matrix cores, fp32 accumulate (fp32-grade, "
                                      "passes the 1e-4 / 0.05 px parity bars)"), "parallelism": f"streams x{world} (no collective in the step)"},

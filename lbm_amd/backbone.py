@@ -88,11 +88,11 @@ class Backbone(nn.Module):
         return None if self._packed is None else self._packed.tokens_split
 
     # -- reference API --------------------------------------------------------------------------
-    def encode_tokens(self, frames: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+    def encode_tokens(self, frames: torch.Tensor, out: torch.Tensor = None, split_out=None) -> torch.Tensor:
         """frames (B,3,H,W) in [0,255] → pyramid token buffer (B, L, C), level 0 = rows [0, h*w).
 
         Levels 1..3 (rows h*w..L) are filled too (average pooling, transformer.py:58-69)."""
-        return self.packed().encode(frames, out)
+        return self.packed().encode(frames, out, split_out)
 
     def encode_frames_online(self, frames: torch.Tensor) -> torch.Tensor:
         """backbone.py:175-193 — returns (B, h*w, C) tokens."""

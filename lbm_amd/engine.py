@@ -109,10 +109,15 @@ class EncoderWeights:
         self.fusion_ws = hip.SplitWeight(self.fusion_w)
         self._scratch = None
         self.tokens_split: Optional[hip.SplitTensor] = None     # split twin of the last encode() output
+        self._own_split: Optional[hip.SplitTensor] = None
+        self._split_target: Optional[hip.SplitTensor] = None
         # positional embedding, token-major (P0, 256)
         self.pos = f32(_f64(bb.frame_pos_embedding)[0].permute(1, 2, 0).reshape(self.P0, -1))
 
-    def encode(self, frames: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def encode(self, frames: torch.Tensor, out: Optional[torch.Tensor] = None,
+               split_out: Optional["hip.SplitTensor"] = None) -> torch.Tensor:
+        """split_out: caller-owned split twin to fill instead of the encoder's own (double-buffered pipelines)."""
+        self._split_target = split_out
         x = hip.preprocess(frames, self.size[0], self.size[1], layout=4)
         return self._body(x, True, out)
 
@@ -174,9 +179,13 @@ class EncoderWeights:
                           bias=self.fusion_b.data_ptr(), Y=out.data_ptr(), res=self.pos.data_ptr() if add_pos else None,
                           M=P0, N=256, K=192, lda=192, ldb=192, ldy=256, ldres=256, res_div=1, res_mod=0, res_scale=1.0, act=1,
                           batch=B, sA=P0 * 192, sB=0, sBias=0, sY=self.L * 256, sR=0)
-        if self.tokens_split is None or self.tokens_split.shape != (B, self.L, 256):
-            self.tokens_split = hip.SplitTensor((B, self.L, 256), self.dev)
-        hip.pyramid_s(out, self.tokens_split, self.h, self.w)
+        target, self._split_target = self._split_target, None
+        if target is None:      # the encoder's own twin; a caller-owned one (pipelined slots) is never reused for another frame
+            if self._own_split is None or self._own_split.shape != (B, self.L, 256):
+                self._own_split = hip.SplitTensor((B, self.L, 256), self.dev)
+            target = self._own_split
+        self.tokens_split = target
+        hip.pyramid_s(out, target, self.h, self.w)
         return out
 
 
@@ -332,8 +341,8 @@ class TrackEngine:
         self.cfg = cfg
         self.w = weights
         self.dev = weights.device
-        self._ws: Optional[torch.Tensor] = None
-        self._ws_key = None
+        self._ws: Dict[int, torch.Tensor] = {}       # workspace per slot (a pipelined caller alternates two)
+        self._ws_key: Dict[int, tuple] = {}
 
     def _desc(self, B: int, N: int, M: int) -> hip.StepDesc:
         cfg = self.cfg
@@ -358,24 +367,29 @@ class TrackEngine:
         d.n_weights = self.w.n
         return d
 
-    def workspace(self, d: hip.StepDesc) -> torch.Tensor:
+    def workspace(self, d: hip.StepDesc, slot: int = 0) -> torch.Tensor:
         key = (d.B, d.N, d.M, d.precision, bool(d.tokens_split))
-        if self._ws is None or self._ws_key != key:
+        if self._ws.get(slot) is None or self._ws_key.get(slot) != key:
             nbytes = int(hip.load().lbm_hip_step_workspace_bytes(C.byref(d)))
             if nbytes == 0:
                 raise hip.HipError("step workspace: " + hip.load().lbm_hip_last_error().decode())
-            self._ws = None
-            self._ws = torch.empty(nbytes, device=self.dev, dtype=torch.uint8)
-            self._ws_key = key
-        return self._ws
+            self._ws[slot] = None
+            self._ws[slot] = torch.empty(nbytes, device=self.dev, dtype=torch.uint8)
+            self._ws_key[slot] = key
+        self._last_slot = slot
+        return self._ws[slot]
 
     def step(self, tokens: torch.Tensor, query: torch.Tensor, stream_mem: torch.Tensor, coll_mem: torch.Tensor,
              vis_mask: torch.Tensor, mem_mask: torch.Tensor, ring_head: int = 0, queried: Optional[torch.Tensor] = None,
              update_state: bool = True, img_hw: Optional[Sequence[int]] = None, want_memory: bool = False,
              want_aux: bool = False, want_corr: bool = False, vis_threshold: float = 0.8,
              tokens_split: Optional["hip.SplitTensor"] = None, phase: int = 0, rows: Optional[Sequence[int]] = None,
-             sub_index: int = 0, out: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
-        """tokens (B,L,256) pyramid; query (B,N,256); memories (B,N,M,256) in ring order; masks (B,N,M) bool/uint8."""
+             sub_index: int = 0, out: Optional[Dict[str, torch.Tensor]] = None, ws_slot: int = 0) -> Dict[str, torch.Tensor]:
+        """tokens (B,L,256) pyramid; query (B,N,256); memories (B,N,M,256) in ring order; masks (B,N,M) bool/uint8.
+
+        phase 0: the whole step.  phase 1: only the point-independent part (value maps, correlation maps) into the
+        workspace of ``ws_slot``; phase 2: only the per-point part, reading that workspace.  A pipelined caller runs
+        phase 1 of frame t+1 on a second stream (and second slot) while phase 2 of frame t is in flight."""
         hip._require_gpu()
         if self.w.memory_size != stream_mem.shape[2]:
             raise hip.HipError(f"memory has {stream_mem.shape[2]} slots but the time embeddings were built for "
@@ -391,9 +405,11 @@ class TrackEngine:
             if tokens_split.shape != tuple(tokens.shape):
                 raise hip.HipError("tokens_split does not match tokens")
             d.tokens_split = tokens_split.hi
-        ws = self.workspace(d)
+        ws = self.workspace(d, ws_slot)
         dev = self.dev
         d.phase, d.sub_index = phase, sub_index
+        if phase == 2 and rows is None:
+            rows = (0, B * N)
         if rows is not None:
             d.row_lo, d.row_count = int(rows[0]), int(rows[1])
         if out is None:
@@ -443,4 +459,4 @@ class TrackEngine:
         if off < 0:
             raise KeyError(name)
         n = int(torch.tensor(shape).prod()) * torch.empty((), dtype=dtype).element_size()
-        return self._ws[off:off + n].view(dtype).view(*shape)
+        return self._ws[self._last_slot][off:off + n].view(dtype).view(*shape)

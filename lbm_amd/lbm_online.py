@@ -50,6 +50,10 @@ class LBM_online(LBM):
         self._g_streams = []
         self._g_fork = None
         self._g_join = []
+        # frame pipeline (prefetch()): encoder stream, two token / workspace slots, hand-over events
+        self._pipe = None
+        self._pf = {}               # frame key -> slot, for the (at most two) frames encoded ahead
+        self.pipelined_frames = 0   # frames whose encoder ran ahead on the encoder stream
         if with_obj_tracker:
             raise NotImplementedError("the object-tracking association layer (object_tracker.py) is outside the hot path "
                                       "(SURVEY §8 f.1); update() below provides the add/remove-points primitive it drives")
@@ -167,19 +171,91 @@ class LBM_online(LBM):
         self.query = self.backbone.sample_points(tok, self._to_net_px(query_points.to(self.device)).contiguous())
         self._alloc_state(B, N)
 
+    # ---- frame pipeline ------------------------------------------------------------------------
+    @staticmethod
+    def _frame_key(frames: torch.Tensor):
+        return (frames.data_ptr(), tuple(frames.shape), tuple(frames.stride()), frames.dtype)
+
+    @torch.no_grad()
+    def prefetch(self, frames: torch.Tensor) -> None:
+        """Start on the frame the NEXT online_forward / online_forward_batch call will be given.
+
+        Everything that does not depend on the tracked points -- the encoder, the six value maps and the correlation
+        maps, about half of a frame's GPU time with one stream of ~1000 points -- is enqueued on a second HIP stream
+        into the other of two token / workspace slots, so it overlaps the per-point chain of the current frame, whose
+        ~120 small dependent launches leave most of the 256 CUs idle.  Results are identical to the unpipelined call
+        (same kernels on the same data); only the time at which they run changes.  The caller must not modify
+        ``frames`` until the matching online_forward call has been made.  No counterpart in the reference, whose
+        frame loop is strictly serial (lbm_online.py:114-158, tools/benchmark_torch.py:71-76)."""
+        if self.query is None or not frames.is_cuda:
+            return
+        main = torch.cuda.current_stream()
+        key = (frames.shape[0], self.N, self.memory_size, frames.device)
+        if self._pipe is None or self._pipe["key"] != key:
+            L = self.transformer.cfg.num_tokens
+            dev = frames.device
+            self._pipe = {
+                "key": key, "stream": torch.cuda.Stream(device=dev), "next": 0,
+                "tok": [torch.empty(frames.shape[0], L, self.embed_dim, device=dev) for _ in range(2)],
+                "tok_s": [None, None],
+                "enc_done": [torch.cuda.Event() for _ in range(2)],
+            }
+        p = self._pipe
+        slot = p["next"]
+        p["next"] = slot ^ 1
+        enc = p["stream"]
+        # the frame was produced on the caller's stream, and the slot's previous reader (the per-point phase two
+        # frames back) was enqueued there as well: one wait covers both
+        enc.wait_stream(main)
+        frames.record_stream(enc)
+        H, W = frames.shape[-2], frames.shape[-1]
+        with torch.cuda.stream(enc):
+            if p["tok_s"][slot] is None and self.backbone.packed().precision == "split":
+                p["tok_s"][slot] = hip.SplitTensor(tuple(p["tok"][slot].shape), frames.device)
+            tok = self.backbone.encode_tokens(frames, p["tok"][slot], split_out=p["tok_s"][slot])
+            self.transformer.get_engine().step(tok, self.query, self._stream, self._coll, self._vis, self._mem,
+                                               ring_head=0, update_state=False, img_hw=(H, W),
+                                               tokens_split=p["tok_s"][slot], phase=1, ws_slot=slot)
+            p["enc_done"][slot].record(enc)
+        self._pf = {k: v for k, v in self._pf.items() if v != slot}
+        self._pf[self._frame_key(frames)] = slot
+
     @torch.no_grad()
     def online_forward_batch(self, frames: torch.Tensor, tokens: Optional[torch.Tensor] = None):
         """frames (B,3,H,W) -> coords (B,N,2) frame px, vis (B,N) bool, rho (B,N) in (0,1), tokens (B,L,C)."""
         H, W = frames.shape[-2], frames.shape[-1]
+        if self._pf:
+            slot = self._pf.pop(self._frame_key(frames), None)
+            p = self._pipe
+            if slot is not None and p is not None and p["key"] == (frames.shape[0], self.N, self.memory_size, frames.device):
+                self.pipelined_frames += 1
+                torch.cuda.current_stream().wait_event(p["enc_done"][slot])
+                tok = p["tok"][slot]
+                out = self.transformer.get_engine().step(tok, self.query, self._stream, self._coll, self._vis, self._mem,
+                                                         ring_head=self._head, queried=None, update_state=True, img_hw=(H, W),
+                                                         vis_threshold=self.visibility_treshold,
+                                                         tokens_split=p["tok_s"][slot], phase=2, ws_slot=slot)
+                self._head = (self._head + 1) % self.memory_size
+                self.t += 1
+                self.last_logits = (out["vis"], out["rho"])
+                if tokens is not None:
+                    tokens.copy_(tok)
+                    tok = tokens
+                return out["coords"], torch.sigmoid(out["vis"]) > self.visibility_treshold, torch.sigmoid(out["rho"]), tok
+        if self._pipe is not None:      # the encoder's scratch is shared: never run it on two streams at once
+            torch.cuda.current_stream().wait_stream(self._pipe["stream"])
         if self.use_graph and frames.is_cuda and self.B * self.N <= self.graph_max_rows and self.N > 0:
             res = self._forward_graph(frames)
             if res is not None:
                 return res
+        # a frame encoded ahead owns its workspace slot until it is consumed: an unpipelined frame in between uses a third
+        busy = set(self._pf.values())
+        ws_slot = next(i for i in (0, 1, 2) if i not in busy)
         tok = self.backbone.encode_tokens(frames, tokens)
         out = self.transformer.get_engine().step(tok, self.query, self._stream, self._coll, self._vis, self._mem,
                                                  ring_head=self._head, queried=None, update_state=True, img_hw=(H, W),
                                                  vis_threshold=self.visibility_treshold,
-                                                 tokens_split=self.backbone.last_tokens_split)
+                                                 tokens_split=self.backbone.last_tokens_split, ws_slot=ws_slot)
         self._head = (self._head + 1) % self.memory_size
         self.t += 1
         self.last_logits = (out["vis"], out["rho"])

@@ -51,6 +51,7 @@ int conv2d_nhwc16(const ConvArgs& c, hipStream_t stream);
 int split_planes(const float* x, void* hi, void* lo, long long n, hipStream_t stream);
 void gemm16_force_tile(int t);
 void gemm16_debug(int flags);
+void conv16_force(int mode);
 
 // Both operands pre-split into f16 planes: Y = act(A · Bᵀ + bias) + res_scale · RES, fp32 and/or split output.
 struct GemmSSArgs {

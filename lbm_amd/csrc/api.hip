@@ -557,6 +557,10 @@ int lbm_hip_debug_set(int32_t key, int32_t value) {
     conv16_force(value);
     return 0;
   }
+  if (key == 5) {
+    topk_force_mode(value);
+    return 0;
+  }
   set_error("debug_set: unknown key %d", key);
   return -1;
 }

@@ -25,38 +25,60 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
   }
 }
 
+// One workgroup per 8x8 block of level-0 cells, one wave per 4x4 quadrant, lane = 4 channels: the 16 level-0 rows of
+// a quadrant are loaded once (all loads in flight), giving its four level-1 cells and its level-2 cell in registers;
+// the level-3 cell is the mean of the four quadrant sums (through LDS).  With `toks` the split twin of every row
+// touched, level 0 included, is emitted on the way.  (The first version walked each output cell's s x s window with
+// dependent loads: 40 us at one 96x128 frame, all of it the 64-load chains of the 192 level-3 cells.)
 __global__ __launch_bounds__(256) void pyramid_pool_kernel(float* __restrict__ tok, int B, int h, int w, int L, void* toks,
                                                            long long toks_plane) {
-  // one 64-lane group per output cell (levels 1..3); lane owns 4 channels
-  const int lane = threadIdx.x & 63;
+  __shared__ float4 part[4][64];
+  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int bw = w >> 3, bh = h >> 3;
   const int P0 = h * w;
-  const int per_stream = L - P0;
-  const long long total = (long long)B * per_stream;
-  for (long long cell = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); cell < total; cell += (long long)gridDim.x * 4) {
-    const int b = (int)(cell / per_stream);
-    int o = (int)(cell % per_stream);
-    int lvl = 1, start = P0;
-    int hl = h >> 1, wl = w >> 1;
-    while (o >= hl * wl) {
-      o -= hl * wl;
-      start += hl * wl;
-      ++lvl;
-      hl >>= 1;
-      wl >>= 1;
+  const int b = blockIdx.x / (bh * bw);
+  const int rem = blockIdx.x - b * (bh * bw);
+  const int by = rem / bw, bx = rem - by * bw;
+  const int y0 = by * 8 + (q >> 1) * 4, x0 = bx * 8 + (q & 1) * 4;
+  float* base = tok + (long long)b * L * LBM_C + lane * 4;
+  const long long sbase = (long long)b * L * LBM_C + lane * 4;
+  float4 v[4][4];
+#pragma unroll
+  for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 4; ++dx) v[dy][dx] = ld4(base + (long long)((y0 + dy) * w + x0 + dx) * LBM_C);
+  if (toks) {
+#pragma unroll
+    for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 4; ++dx) st4_split(toks, toks_plane, sbase + (long long)((y0 + dy) * w + x0 + dx) * LBM_C, v[dy][dx]);
+  }
+  auto add = [](float4 a, const float4 c) { a.x += c.x; a.y += c.y; a.z += c.z; a.w += c.w; return a; };
+  auto mul = [](const float4 a, float f) { return make_float4(a.x * f, a.y * f, a.z * f, a.w * f); };
+  auto put = [&](long long cell, const float4 o) {
+    st4(base + cell * LBM_C, o);
+    if (toks) st4_split(toks, toks_plane, sbase + cell * LBM_C, o);
+  };
+  // level 1: 2x2 windows, summed in row-major order
+  const int w1 = w >> 1, w2 = w >> 2, w3 = w >> 3;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float4 s4 = add(add(add(v[2 * i][2 * j], v[2 * i][2 * j + 1]), v[2 * i + 1][2 * j]), v[2 * i + 1][2 * j + 1]);
+      put(P0 + (long long)((y0 >> 1) + i) * w1 + (x0 >> 1) + j, mul(s4, 0.25f));
     }
-    const int s = 1 << lvl;
-    const int y = o / wl, x = o % wl;
-    const float* src = tok + (long long)b * L * LBM_C + lane * 4;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int dy = 0; dy < s; ++dy)
-      for (int dx = 0; dx < s; ++dx) {
-        const float4 v = ld4(src + (long long)((y * s + dy) * w + x * s + dx) * LBM_C);
-        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-      }
-    const float inv = 1.0f / (float)(s * s);
-    const float4 v = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
-    st4(tok + ((long long)b * L + start + o) * LBM_C + lane * 4, v);
-    if (toks) st4_split(toks, toks_plane, ((long long)b * L + start + o) * LBM_C + lane * 4, v);
+  // level 2: the 4x4 window, row-major
+  float4 s16 = v[0][0];
+#pragma unroll
+  for (int t = 1; t < 16; ++t) s16 = add(s16, v[t >> 2][t & 3]);
+  put(P0 + (P0 >> 2) + (long long)(y0 >> 2) * w2 + (x0 >> 2), mul(s16, 1.0f / 16.0f));
+  // level 3: the four quadrant sums
+  part[q][lane] = s16;
+  __syncthreads();
+  if (q == 0) {
+    const float4 s64 = add(add(add(part[0][lane], part[1][lane]), part[2][lane]), part[3][lane]);
+    put(P0 + (P0 >> 2) + (P0 >> 4) + (long long)by * w3 + bx, mul(s64, 1.0f / 64.0f));
   }
 }
 
@@ -64,19 +86,11 @@ int pyramid_pool(float* tokens, int B, int h, int w, hipStream_t stream, void* t
   LBM_REQUIRE(tokens && B > 0 && h % 8 == 0 && w % 8 == 0, "pyramid_pool: grid %dx%d must be a multiple of 8", h, w);
   const int P0 = h * w;
   const int L = P0 + P0 / 4 + P0 / 16 + P0 / 64;
-  long long blocks = ((long long)B * (L - P0) + 3) / 4;
-  if (blocks > 16384) blocks = 16384;
-  ProfScope prof("pyramid_pool", stream, 0.0, 4.0 * LBM_C * B * ((double)P0 + (L - P0)));
+  const long long blocks = (long long)B * (h / 8) * (w / 8);
+  LBM_REQUIRE(blocks < 0x7fffffffLL, "pyramid_pool: too many blocks");
+  ProfScope prof("pyramid_pool", stream, 0.0, 4.0 * LBM_C * B * ((double)P0 + (L - P0)) * (toks ? 2.0 : 1.0));
   hipLaunchKernelGGL(pyramid_pool_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, tokens, B, h, w, L, toks, toks_plane);
-  if (check_launch("pyramid_pool")) return -1;
-  if (toks) {   // level 0 rows of every stream (levels 1..3 were emitted above)
-    long long rb = ((long long)B * P0 + 3) / 4;
-    if (rb > 32768) rb = 32768;
-    ProfScope prof2("split_rows", stream, 0.0, 8.0 * LBM_C * B * P0);
-    hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)rb), dim3(256), 0, stream, tokens, toks, toks_plane, B, P0, L);
-    return check_launch("split_rows");
-  }
-  return 0;
+  return check_launch("pyramid_pool");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -336,6 +350,196 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
   }
 }
 
+// Few rows (one stream, ~1000 points): one 256-thread workgroup per row, the row held in registers (<= 16 float4 per
+// thread), so it is read ONCE.  tau = the largest, over the four waves, of the k-th largest per-lane maximum is a lower
+// bound of the k-th largest element; the elements >= tau are compacted into LDS.  Up to 256 of them (peaky maps) are
+// ranked directly (rank = number of candidates that precede it in (value desc, index asc) order).  Broad maxima leave
+// more: then the k-th largest value T is found exactly by bisection on the order-preserving integer image of the
+// values (largest T with >= k elements >= T) and the ties at T are cut by bisection on the index (lowest first) --
+// over the <= 1024 candidates (4 per thread) when they fit, over the whole row in registers otherwise (flat rows).
+__device__ __forceinline__ unsigned topk_key(float v) {
+  const unsigned u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float topk_unkey(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
+template <int NV>
+__global__ __launch_bounds__(256) void topk_rows_wide_kernel(const float* __restrict__ corr, long long ld, int P, int k, int rows,
+                                                            int grid_w, float cell, int* __restrict__ idx_out,
+                                                            float* __restrict__ ref_out, float* __restrict__ val_out) {
+  constexpr int CAP = 1024;
+  __shared__ float s_tau[4];
+  __shared__ float s_red[2][4];
+  __shared__ int s_cnt;
+  __shared__ float s_v[CAP];
+  __shared__ int s_i[CAP];
+  __shared__ float s_fv[64];
+  __shared__ int s_fi[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row = blockIdx.x;
+  const int nvec = P >> 2;
+  const float* src = corr + (long long)row * ld;
+  float4 buf[NV];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int f = tid + j * 256;
+    buf[j] = f < nvec ? ld4(src + f * 4) : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    mx = fmaxf(fmaxf(mx, fmaxf(buf[j].x, buf[j].y)), fmaxf(buf[j].z, buf[j].w));
+  }
+  const float rmax_w = wave_max(mx);
+  float tau = -INFINITY;
+  for (int t = 0; t < k; ++t) {        // k rounds: wave max, then the (first) lane holding it drops out
+    tau = wave_max(mx);
+    const unsigned long long holders = __ballot(mx == tau);
+    if (lane == __builtin_ctzll(holders)) mx = -INFINITY;
+  }
+  if (lane == 0) {
+    s_tau[wave] = tau;
+    s_red[0][wave] = rmax_w;
+  }
+  if (tid == 0) s_cnt = 0;
+  __syncthreads();
+  tau = fmaxf(fmaxf(s_tau[0], s_tau[1]), fmaxf(s_tau[2], s_tau[3]));
+  const float rmax = fmaxf(fmaxf(s_red[0][0], s_red[0][1]), fmaxf(s_red[0][2], s_red[0][3]));
+  auto push = [&](float v, int i) {
+    if (v >= tau) {
+      const int p = atomicAdd(&s_cnt, 1);
+      if (p < CAP) {
+        s_v[p] = v;
+        s_i[p] = i;
+      }
+    }
+  };
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    if (fmaxf(fmaxf(buf[j].x, buf[j].y), fmaxf(buf[j].z, buf[j].w)) >= tau) {
+      const int i0 = (tid + j * 256) * 4;
+      push(buf[j].x, i0);
+      push(buf[j].y, i0 + 1);
+      push(buf[j].z, i0 + 2);
+      push(buf[j].w, i0 + 3);
+    }
+  }
+  __syncthreads();
+  const int n = s_cnt;
+  auto emit = [&](int t, float bv, int bi) {
+    const long long o = (long long)row * k + t;
+    idx_out[o] = bi;
+    if (ref_out) {
+      ref_out[o * 2 + 0] = (float)(bi % grid_w) * cell + 0.5f * cell;   // coord_utils.py:20-21
+      ref_out[o * 2 + 1] = (float)(bi / grid_w) * cell + 0.5f * cell;
+    }
+    if (val_out) val_out[o] = bv;
+  };
+  // rank the m <= 64 entries of (fv, fi) and write the first k in order
+  auto rank_emit = [&](const float* fv, const int* fi, int m) {
+    if (tid < m) {
+      const float mv = fv[tid];
+      const int mi = fi[tid];
+      int rank = 0;
+      for (int q = 0; q < m; ++q) {
+        const float ov = fv[q];
+        const int oi = fi[q];
+        rank += (ov > mv || (ov == mv && oi < mi)) ? 1 : 0;
+      }
+      if (rank < k) emit(rank, mv, mi);
+    }
+  };
+  if (n <= 64) {
+    rank_emit(s_v, s_i, n);
+    return;
+  }
+  if (n <= 256) {
+    if (tid < n) {
+      const float mv = s_v[tid];
+      const int mi = s_i[tid];
+      int rank = 0;
+      for (int q = 0; q < n; ++q) {
+        const float ov = s_v[q];
+        const int oi = s_i[q];
+        rank += (ov > mv || (ov == mv && oi < mi)) ? 1 : 0;
+      }
+      if (rank < k) emit(rank, mv, mi);
+    }
+    return;
+  }
+
+  int flip = 1;                                   // s_red[0] was read above; every thread is past the barrier after it
+  auto block_sum = [&](int c) {
+    const float w = wave_sum((float)c);           // <= 64 * 64 per wave: exact in fp32
+    if (lane == 0) s_red[flip][wave] = w;
+    __syncthreads();
+    const int tot = (int)(s_red[flip][0] + s_red[flip][1] + s_red[flip][2] + s_red[flip][3]);
+    flip ^= 1;                                    // the next sum writes the other slot: one barrier per sum suffices
+    return tot;
+  };
+  // exact selection among this thread's NE elements (keys ke[], indices ie[]; key 0 / index INT_MAX = no element)
+  auto select = [&](const auto& ke, const auto& ie) {
+    constexpr int NE = sizeof(ke) / sizeof(ke[0]);
+    auto count_ge = [&](unsigned t) {
+      int c = 0;
+#pragma unroll
+      for (int e = 0; e < NE; ++e) c += ke[e] >= t ? 1 : 0;
+      return block_sum(c);
+    };
+    unsigned lo = topk_key(tau), hi = topk_key(rmax);
+    while (lo < hi) {
+      const unsigned mid = lo + (hi - lo + 1) / 2;
+      if (count_ge(mid) >= k) lo = mid; else hi = mid - 1;
+    }
+    const unsigned T = lo;
+    const int need = k - (T == 0xffffffffu ? 0 : count_ge(T + 1));     // how many of the elements equal to T are taken
+    int jlo = 0, jhi = P - 1;
+    while (jlo < jhi) {
+      const int jm = (jlo + jhi) >> 1;
+      int c = 0;
+#pragma unroll
+      for (int e = 0; e < NE; ++e) c += (ke[e] == T && ie[e] <= jm) ? 1 : 0;
+      if (block_sum(c) >= need) jhi = jm; else jlo = jm + 1;
+    }
+    const int J = jlo;
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      if (ke[e] > T || (ke[e] == T && ie[e] <= J)) {
+        const int p = atomicAdd(&s_cnt, 1);
+        if (p < 64) {
+          s_fv[p] = topk_unkey(ke[e]);
+          s_fi[p] = ie[e];
+        }
+      }
+    }
+    __syncthreads();
+    rank_emit(s_fv, s_fi, min(s_cnt, 64));
+  };
+  if (n <= CAP) {
+    unsigned ke[CAP / 256];
+    int ie[CAP / 256];
+#pragma unroll
+    for (int q = 0; q < CAP / 256; ++q) {
+      const int p = tid + q * 256;
+      ke[q] = p < n ? topk_key(s_v[p]) : 0u;
+      ie[q] = p < n ? s_i[p] : 0x7fffffff;
+    }
+    select(ke, ie);
+  } else {
+    unsigned ke[NV * 4];
+    int ie[NV * 4];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int i0 = (tid + j * 256) * 4;
+      const bool in = i0 < P;
+      ke[4 * j + 0] = in ? topk_key(buf[j].x) : 0u; ie[4 * j + 0] = in ? i0 : 0x7fffffff;
+      ke[4 * j + 1] = in ? topk_key(buf[j].y) : 0u; ie[4 * j + 1] = in ? i0 + 1 : 0x7fffffff;
+      ke[4 * j + 2] = in ? topk_key(buf[j].z) : 0u; ie[4 * j + 2] = in ? i0 + 2 : 0x7fffffff;
+      ke[4 * j + 3] = in ? topk_key(buf[j].w) : 0u; ie[4 * j + 3] = in ? i0 + 3 : 0x7fffffff;
+    }
+    select(ke, ie);
+  }
+}
+
 template <int KMAX>
 static void launch_topk(bool wide, dim3 grid, hipStream_t stream, const float* corr, long long ld, int P, int k, int rows, int grid_w,
                         float cell, int* idx_out, float* ref_out, float* val_out) {
@@ -344,6 +548,9 @@ static void launch_topk(bool wide, dim3 grid, hipStream_t stream, const float* c
   else
     hipLaunchKernelGGL((topk_rows_kernel<KMAX, 1>), grid, dim3(256), 0, stream, corr, ld, P, k, rows, grid_w, cell, idx_out, ref_out, val_out);
 }
+
+static int g_topk_mode = 0;
+void topk_force_mode(int m) { g_topk_mode = m; }
 
 int topk_rows(const float* corr, long long ld, int P, int k, int rows, int grid_w, int stride_px, int* idx_out,
               float* ref_out, float* val_out, hipStream_t stream) {
@@ -354,7 +561,17 @@ int topk_rows(const float* corr, long long ld, int P, int k, int rows, int grid_
   const bool wide = rows < 4096 && P >= 1024;        // few rows: four waves per row
   dim3 grid(wide ? rows : (rows + 3) / 4);
   const float cell = (float)stride_px;
-  ProfScope prof("topk_rows", stream, 0.0, 4.0 * rows * ((double)P + 4.0 * k));
+  ProfScope prof(k == 1 ? "topk_rows_k1" : k <= 4 ? "topk_rows_k4" : k <= 9 ? "topk_rows_k9" : "topk_rows_k16", stream, 0.0,
+                 4.0 * rows * ((double)P + 4.0 * k));
+  if (wide && P % 4 == 0 && P <= 16 * 1024 && g_topk_mode == 0) {   // the row fits the registers of one workgroup
+    if (P <= 4 * 1024)
+      hipLaunchKernelGGL((topk_rows_wide_kernel<4>), grid, dim3(256), 0, stream, corr, ld, P, k, rows, grid_w, cell, idx_out, ref_out, val_out);
+    else if (P <= 12 * 1024)
+      hipLaunchKernelGGL((topk_rows_wide_kernel<12>), grid, dim3(256), 0, stream, corr, ld, P, k, rows, grid_w, cell, idx_out, ref_out, val_out);
+    else
+      hipLaunchKernelGGL((topk_rows_wide_kernel<16>), grid, dim3(256), 0, stream, corr, ld, P, k, rows, grid_w, cell, idx_out, ref_out, val_out);
+    return check_launch("topk_rows");
+  }
   if (k == 1) launch_topk<1>(wide, grid, stream, corr, ld, P, k, rows, grid_w, cell, idx_out, ref_out, val_out);
   else if (k <= 4) launch_topk<4>(wide, grid, stream, corr, ld, P, k, rows, grid_w, cell, idx_out, ref_out, val_out);
   else if (k <= 9) launch_topk<9>(wide, grid, stream, corr, ld, P, k, rows, grid_w, cell, idx_out, ref_out, val_out);

@@ -16,4 +16,6 @@ int corr_maps(const float* tokens, float* inv_norm, float* F, const float* wmix_
 int topk_rows(const float* corr, long long ld, int P, int k, int rows, int grid_w, int stride_px, int* idx_out,
               float* ref_out, float* val_out, hipStream_t stream);
 
+void topk_force_mode(int m);   // tuning: 1 = the per-lane-list kernels for every shape
+
 }  // namespace lbm

@@ -62,5 +62,12 @@ int main() {
     printf("%-28s: 1024x1024x256 %6.2f   1024x256x(4x256) %6.2f\n", names[i], t1, t2);
   }
   lbm_hip_debug_set(2, 0);
+  d.act = 0;
+  printf("1024x1024x256 split out, no GELU      : %6.2f\n", time_us([&] { lbm_hip_linear_ss(&d, s); }, N, s));
+  d.Y = X; d.Ys = nullptr;
+  printf("1024x1024x256 fp32 out, no GELU       : %6.2f\n", time_us([&] { lbm_hip_linear_ss(&d, s); }, N, s));
+  d.Ys = Hs;
+  printf("1024x1024x256 fp32 + split, no GELU   : %6.2f\n", time_us([&] { lbm_hip_linear_ss(&d, s); }, N, s));
+  d.M = 16384; d.Y = nullptr; d.act = 1;   // buffers are large enough: 16384 x 1024 split = 64 MB
   return 0;
 }

@@ -132,6 +132,31 @@ def test_topk_is_exact_with_lowest_index_ties(hip, k, rows):
     _cmp(refp[..., 1], (order // 64) * 4 + 2.0, rtol=0, atol=0)
 
 
+@pytest.mark.parametrize("k", [1, 4, 9, 16])
+@pytest.mark.parametrize("P", [1024, 12288, 16384, 4100])
+def test_topk_broad_and_flat_maxima(hip, k, P):
+    """Rows whose k-th largest value is shared or nearly shared by hundreds of cells (smooth maps, quantised values,
+    constant rows, plateaus that straddle the k-th place): the register-resident kernel must leave its candidate list
+    for the exact bisection and still return torch.topk's set with ties to the lowest index."""
+    r = np.random.default_rng(k + P)
+    rows = 12
+    c = r.normal(size=(rows, P)).astype(np.float32)
+    x = np.arange(P, dtype=np.float32)
+    c[0] = np.cos(x / P * 6.0)                                   # smooth, broad maximum
+    c[1] = np.round(c[1] * 2) / 2                                # heavy quantisation: thousands of ties
+    c[2] = 0.25                                                  # constant row
+    c[3] = -np.abs(c[3])
+    c[3, 5:P:3] = 0.0                                            # plateau of zeros at the top
+    c[4, :] = -1.0
+    c[4, P - 7:] = 3.0                                           # fewer than k above a flat floor (for k > 7)
+    c[5] = np.where(x % 2 == 0, 1.0, 1.0 - 2.0 ** -23).astype(np.float32)   # two adjacent float values only
+    c[6] = -np.float32(1e30) * (1 + x % 5)                       # large negative values
+    idx, refp, val = hip.topk(torch.from_numpy(c).cuda(), k, grid_w=64)
+    order = np.lexsort((np.arange(P)[None, :].repeat(rows, 0), -c), axis=1)[:, :k]
+    assert (idx.cpu().numpy() == order).all()
+    _cmp(val, np.take_along_axis(c, order, 1), rtol=0, atol=0)
+
+
 def test_msda_operator_against_reference_golden(hip, golden):
     """The operator seam: MultiScaleDeformableAttention.forward (msdeformattn.py:85-185)."""
     from lbm_amd.msdeformattn import MultiScaleDeformableAttention

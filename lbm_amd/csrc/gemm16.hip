@@ -395,7 +395,7 @@ struct GemmSSDev {
   float res_scale;
   int act;
   long long sA, sB, sBias, sY, sYs, sR;   // batch strides (elements)
-  int dbg;   // ablation switches (tuning only): 1 = no DMA after the prologue (FULL: none at all), 2 = no MFMA, 4 = no output stores, 8 = return at once
+  int dbg;   // ablation switches (tuning only): 1 = no DMA after the prologue (FULL: none at all), 2 = no MFMA, 4 = no output stores, 8 = return at once, 16 = direct epilogue
   // implicit-GEMM convolution (CONV): A is an NHWC activation as split planes [B, cH, cW, Cin], Cin a multiple of 32;
   // row m = (b, oy, ox), column k = (ky, kx, ci).  Taps outside the image read `zeros` (>= 16 zero bytes).
   int cH, cW, cin_log2, ckw, cstride, cpad, cHo, cWo;
@@ -834,7 +834,10 @@ int conv2d_nhwc_ss(const ConvSSArgs& c, hipStream_t stream) {
       default: break;
     }
   }
-  if (c.scratch != nullptr && mid <= 320) {
+  // measured (scripts/conv_bench.py, one 384x512 frame): with >= 128 tiles the unsplit 4-stage pipeline beats K-split +
+  // slab reduction (17 vs 22 us at 96x128x64 -> 64), and a K of <= 4 chunks is never worth splitting (7.5 vs 11 us)
+  const bool keep_whole = nk <= 4 || (mid >= 128 && !full_ok(nk));
+  if (c.scratch != nullptr && mid <= 320 && !keep_whole) {
     // few output pixels: cut K into chunks of at most 9 x 32 that the full-prefetch kernel keeps resident in LDS
     for (int cand = 1; cand <= 16; ++cand) {
       if (nk % cand != 0 || (unsigned long long)cand * M * c.Cout * sizeof(float) > c.scratch_bytes) continue;
@@ -853,7 +856,8 @@ int conv2d_nhwc_ss(const ConvSSArgs& c, hipStream_t stream) {
       const int rc = launch_full<true>(d, 1, stream, &handled);
       if (handled) return rc;
     }
-    return (big >= 128 && c.Cout > 64) ? launch_ss<128, 128, 2, 4, 2, true>(d, 1, stream) : launch_ss<64, 64, 2, 2, 2, true>(d, 1, stream);
+    if (big >= 128 && c.Cout > 64) return launch_ss<128, 128, 2, 4, 2, true>(d, 1, stream);
+    return mid <= 320 ? launch_ss<64, 64, 2, 2, 4, true>(d, 1, stream) : launch_ss<64, 64, 2, 2, 2, true>(d, 1, stream);
   }
   d.Y = (float*)c.scratch; d.sY = M * c.Cout; d.K = K / nsplit; d.kt0_per_z = nk / nsplit; d.act = ACT_NONE;
   {

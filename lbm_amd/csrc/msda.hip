@@ -18,14 +18,17 @@ __device__ __forceinline__ int sel4(const int (&v)[4], int l) {
   return l == 0 ? v[0] : (l == 1 ? v[1] : (l == 2 ? v[2] : v[3]));
 }
 
-template <bool EXPLICIT>
+// PT: compile-time number of points per level (0 = a.P at run time).  blockIdx.y selects the reference point: the k
+// lattice cells of a point are independent gathers, and one workgroup walking them in turn was bound by the latency of
+// its ~36 dependent-address loads per cell (106 us at 1024 points x 9 cells); the cheap stage 1 is simply repeated.
+template <bool EXPLICIT, int PT>
 __global__ __launch_bounds__(256) void msda_sample_kernel(MsdaArgs a) {
   __shared__ float sm[LBM_HEADS][3][64];
   const int lane = threadIdx.x & 63;
   const int hd = threadIdx.x >> 6;
   const long long r = blockIdx.x;
   const int b = (int)(r / a.N);
-  const int P = a.P;
+  const int P = PT ? PT : a.P;
   const int S = LBM_LEVELS * P;
 
   // ---- stage 1: per-sample normalised offset (or location) and attention weight ----
@@ -59,7 +62,8 @@ __global__ __launch_bounds__(256) void msda_sample_kernel(MsdaArgs a) {
   // ---- stage 2: gather ----
   const int tap = lane >> 4, tx = tap & 1, ty = tap >> 1, cq = lane & 15;
   const float* vb = a.value + (long long)b * a.v_batch_stride + hd * LBM_HD + cq * 4;
-  for (int kk = 0; kk < a.k; ++kk) {
+  {
+    const int kk = blockIdx.y;
     float rx = 0.f, ry = 0.f;
     if (!EXPLICIT) {
       const float* rp = a.ref + (r * a.k + kk) * 2;
@@ -71,8 +75,8 @@ __global__ __launch_bounds__(256) void msda_sample_kernel(MsdaArgs a) {
     for (int l = 0; l < LBM_LEVELS; ++l) {
       const int hl = a.lvl_h[l], wl = a.lvl_w[l], st = a.lvl_start[l];
       const float fw = (float)wl, fh = (float)hl;
-#pragma unroll 3
-      for (int p = 0; p < P; ++p) {
+#pragma unroll
+      for (int p = 0; p < (PT ? PT : P); ++p) {
         const int i = l * P + p;
         const float lx = rx + sm[hd][0][i];
         const float ly = ry + sm[hd][1][i];
@@ -125,11 +129,15 @@ int msda_sample(const MsdaArgs& a, hipStream_t stream) {
                  (double)R * a.k * (16.0 * a.P * 4 * 64 * 4 + 4.0 * LBM_C));
   if (explicit_mode) {
     LBM_REQUIRE(a.attw != nullptr && a.k == 1, "msda_sample: explicit mode needs attw and k == 1");
-    hipLaunchKernelGGL(msda_sample_kernel<true>, dim3((unsigned)R), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((msda_sample_kernel<true, 0>), dim3((unsigned)R, 1), dim3(256), 0, stream, a);
   } else {
     LBM_REQUIRE(a.offlog && a.ref && a.net_w > 0.f && a.net_h > 0.f, "msda_sample: implicit mode needs offlog/ref/net size");
     LBM_REQUIRE(a.ld_offlog >= a.logit_col + 16 * a.P && a.logit_col >= 32 * a.P, "msda_sample: offlog layout too small");
-    hipLaunchKernelGGL(msda_sample_kernel<false>, dim3((unsigned)R), dim3(256), 0, stream, a);
+    LBM_REQUIRE(a.k <= 65535, "msda_sample: k=%d too large", a.k);
+    const dim3 grid((unsigned)R, (unsigned)a.k);
+    if (a.P == 9) hipLaunchKernelGGL((msda_sample_kernel<false, 9>), grid, dim3(256), 0, stream, a);
+    else if (a.P == 4) hipLaunchKernelGGL((msda_sample_kernel<false, 4>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((msda_sample_kernel<false, 0>), grid, dim3(256), 0, stream, a);
   }
   return check_launch("msda_sample");
 }

@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import pathlib
 import os
 import statistics
 import sys
@@ -239,6 +240,15 @@ def main():
                 ach = dom["bytes"] / sec / 1e9
                 line["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                     "frac": ach / HBM_PEAK_GBS, "traffic": None}
+            # HBM-side bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate
+            # runs, gfx950 corrections applied by scripts/pmc_traffic.py); counters cannot be read from inside this process
+            pmc = sorted((pathlib.Path(__file__).parent / "profiles").glob(f"r*_{args.workload}_pmc.json"))
+            if pmc:
+                ent = json.loads(pmc[-1].read_text())["kernels"].get(dom["name"])
+                if ent:
+                    line["roofline"]["traffic"] = ent["traffic_bytes_per_launch"]
+                    line["roofline"]["traffic_source"] = f"profiles/{pmc[-1].name}"
+                    line["roofline"]["algorithmic_bytes_per_launch"] = dom["bytes"] / max(dom["launches"], 1)
             line["roofline"]["kernel"] = dom["name"]
             line["roofline"]["avg_launch_us"] = dom["avg_us"]
             line["roofline"]["launches_per_step"] = dom["launches"] / max(1, min(args.steps, 20))

@@ -21,7 +21,7 @@ extern "C" {
 
 typedef void* lbm_stream_t; /* hipStream_t */
 
-#define LBM_HIP_ABI_VERSION 1
+#define LBM_HIP_ABI_VERSION 2
 #define LBM_HIP_MAX_LAYERS 8
 
 int lbm_hip_version(void);
@@ -177,7 +177,9 @@ int lbm_hip_pyramid_s(float* tokens, void* tokens_s, int64_t tokens_plane, int32
 #define LBM_W_ATTN_F2B 10
 #define LBM_W_ATTN_LN2G 11
 #define LBM_W_ATTN_LN2B 12
-#define LBM_W_ATTN_COUNT 13
+#define LBM_W_ATTN_HMSUM 13  /* [256,256] sum over the heads of the HM blocks: the whole read-out when the key sequence has
+                              * ONE element (soft-max over one key is exactly 1, transformer.py:333 at top-k = 1)        */
+#define LBM_W_ATTN_COUNT 14
 
 #define LBM_W_MSDA_OLW 0    /* [48P,256] sampling_offsets (32P rows) then attention_weights (16P rows) */
 #define LBM_W_MSDA_OLB 1
@@ -195,12 +197,12 @@ int lbm_hip_pyramid_s(float* tokens, void* tokens_s, int64_t tokens_plane, int32
 
 /* per layer i, base = i * LBM_W_LAYER_COUNT */
 #define LBM_W_LAYER_COLL 0
-#define LBM_W_LAYER_STREAM 13
-#define LBM_W_LAYER_LATTICE 26
-#define LBM_W_LAYER_UPDATE 38
-#define LBM_W_LAYER_RHO_W 51  /* [1,256] reference_rho */
-#define LBM_W_LAYER_RHO_B 52
-#define LBM_W_LAYER_COUNT 53
+#define LBM_W_LAYER_STREAM 14
+#define LBM_W_LAYER_LATTICE 28
+#define LBM_W_LAYER_UPDATE 40
+#define LBM_W_LAYER_RHO_W 54  /* [1,256] reference_rho */
+#define LBM_W_LAYER_RHO_B 55
+#define LBM_W_LAYER_COUNT 56
 /* after the layers, base = n_layers * LBM_W_LAYER_COUNT */
 #define LBM_W_HEAD_OFFSET 0
 #define LBM_W_HEAD_CMEM 12

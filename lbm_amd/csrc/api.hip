@@ -141,6 +141,7 @@ static int build_layout(const lbm_hip_step_desc* d, StepLayout& lay) {
     lay.add("tb_s", (unsigned long long)lay.R * LBM_C * f);
     lay.add("tc_s", (unsigned long long)lay.R * LBM_C * f);
     lay.add("la_s", (unsigned long long)lay.Q * LBM_C * f);
+    lay.add("lb_s", (unsigned long long)lay.Q * LBM_C * f);
   }
   return 0;
 }
@@ -247,13 +248,23 @@ struct Step {
 
   // memory / lattice-update attention block: x_in [R,256] -> x_out [R,256]
   int attn_block(int wb, const TV& x_in, const TV& x_out, const float* seq, long long point_stride, int S, int ring_head,
-                 bool masked, const TV* Yn) {
+                 bool masked, const TV* Yn, const TV* seq_tv = nullptr) {
     const int km = (int)lay.kmax;
     TV U = view("U", nullptr, 1, 1, 1024);
     TV mbar = view1("mbar", 1, 1, 1024);
     TV hid = view1("hid", km, 1, 1024);
     TV y = view("tc", "tc_s", 1, 1, LBM_C);
     uint8_t* valid = masked ? buf<uint8_t>("valid") + lo : nullptr;
+    if (!masked && S == 1 && seq_tv != nullptr) {
+      // one key: its soft-max weight is exactly 1 in every head, so the read-out is the key itself and
+      // Hm . [key; key; key; key] = (sum over heads of the Hm blocks) . key -- no query projection, no read-out, K = 256
+      if (linear_ln(*seq_tv, LBM_C, wb + LBM_W_ATTN_HMSUM, wb + LBM_W_ATTN_HB, 1, R, LBM_C, x_in.f, 1, 1.f, wb + LBM_W_ATTN_LN1G,
+                    wb + LBM_W_ATTN_LN1B, y))
+        return -1;
+      if (linear(y, LBM_C, wb + LBM_W_ATTN_F1W, wb + LBM_W_ATTN_F1B, hid, 1024, R, 1024, LBM_C, ACT_GELU)) return -1;
+      return linear_ln(hid, 1024, wb + LBM_W_ATTN_F2W, wb + LBM_W_ATTN_F2B, 1, R, 1024, y.f, 1, 1.f, wb + LBM_W_ATTN_LN2G,
+                       wb + LBM_W_ATTN_LN2B, x_out, valid, x_in.f, Yn);
+    }
     if (linear(x_in, LBM_C, wb + LBM_W_ATTN_G, wb + LBM_W_ATTN_GB, U, 1024, R, 1024, LBM_C)) return -1;
     AttnArgs a;
     a.U = U.f; a.seq = seq; a.point_stride = point_stride; a.slot_stride = LBM_C; a.S = S; a.ring_head = ring_head;
@@ -348,7 +359,7 @@ struct Step {
     for (int i = 0; i < d->n_layers; ++i) {
       const int lw = i * LBM_W_LAYER_COUNT;
       const int k = d->topk[i];
-      TV lb = view("lb", nullptr, (int)lay.kmax, k, LBM_C);
+      TV lb = view("lb", k == 1 ? "lb_s" : nullptr, (int)lay.kmax, k, LBM_C);   // split twin only where a GEMM consumes it
       // collision then streaming read-out of the two memories (transformer.py:257-302)
       if (attn_block(lw + LBM_W_LAYER_COLL, x, ta, coll_mem, (long long)M * LBM_C, M, d->ring_head, true, nullptr)) return -1;
       if (attn_block(lw + LBM_W_LAYER_STREAM, ta, tb, stream_mem, (long long)M * LBM_C, M, d->ring_head, true, &qn)) return -1;
@@ -385,7 +396,7 @@ struct Step {
       }
       // lattice update (transformer.py:330-338)
       const TV& xn = (i & 1) ? x1 : x0;
-      if (attn_block(lw + LBM_W_LAYER_UPDATE, tb, xn, lb.f, (long long)k * LBM_C, k, 0, false, nullptr)) return -1;
+      if (attn_block(lw + LBM_W_LAYER_UPDATE, tb, xn, lb.f, (long long)k * LBM_C, k, 0, false, nullptr, &lb)) return -1;
       x = xn;
       if (i == d->n_layers - 1 && rdst != ref) {
         if (hipMemcpyAsync(ref, rdst, (size_t)R * 2 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) {

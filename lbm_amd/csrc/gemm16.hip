@@ -636,6 +636,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_ss_kernel(GemmSSDev a) {
   if constexpr (FULL) {
     pf_steps<0, STAGES, PPW>(compute);
   } else {
+    // The DMA of chunk kt+STAGES-1 is issued BEFORE this chunk's wait and barrier (its stage was released by the barrier
+    // that closes the previous iteration).  A one-barrier form that issues it after the barrier measured 15-25 % slower on
+    // the large grids (64 -> 81 us at 16320 x 1536 x 256): the issue-to-landing latency is what the loop is exposed to.
     for (int kt = 0; kt < nk; ++kt) {
       const int pre = kt + STAGES - 1;
       if (pre < nk && !(a.dbg & 1)) {
@@ -919,6 +922,10 @@ int gemm_ss(const GemmSSArgs& a, hipStream_t stream) {
     case 14: return launch_ss<64, 128, 2, 2, 4>(d, a.batch, stream);
     case 15: return launch_ss<128, 64, 4, 2, 4>(d, a.batch, stream);
     case 16: return launch_ss<64, 256, 2, 4, 3>(d, a.batch, stream);
+    case 17: return launch_ss<128, 64, 2, 2, 3>(d, a.batch, stream);
+    case 18: return launch_ss<128, 64, 4, 2, 3>(d, a.batch, stream);
+    case 19: return launch_ss<64, 128, 2, 4, 3>(d, a.batch, stream);
+    case 21: return launch_ss<128, 128, 4, 2, 2>(d, a.batch, stream);
     default: break;
   }
   set_error("gemm_ss: unknown tiling %d", t);

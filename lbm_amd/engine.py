@@ -246,6 +246,7 @@ class TrackerWeights:
                 put(base + k["LBM_W_ATTN_TEMB"], temb[0, :-1])
             put(base + k["LBM_W_ATTN_HM"], Hm)
             put(base + k["LBM_W_ATTN_HB"], hb)
+            put(base + k["LBM_W_ATTN_HMSUM"], Hm.double().view(Hm.shape[0], cfg.num_heads, -1).sum(1).float())
             put(base + k["LBM_W_ATTN_LN1G"], ln1.weight)
             put(base + k["LBM_W_ATTN_LN1B"], ln1.bias)
             put(base + k["LBM_W_ATTN_F1W"], ffn.net[0].weight)

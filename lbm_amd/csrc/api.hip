@@ -147,6 +147,8 @@ static int build_layout(const lbm_hip_step_desc* d, StepLayout& lay) {
 }
 
 // A tensor view used by the step: fp32 rows and/or the same values as split f16 planes (hi at `s`, lo at s + plane).
+static int g_fuse_kmax_small = 1;   // tuning (debug key 6): largest k fused into the correlation product at < 4096 rows
+
 struct TV {
   float* f = nullptr;
   void* s = nullptr;
@@ -366,6 +368,8 @@ struct Step {
       // correlation + top-k (transformer.py:306-308)
       float* cdst = d->corr[i] ? d->corr[i] + (long long)lo * lay.P0 : corr;
       const int gm = one ? R : d->N, gb = one ? 1 : d->B;
+      bool fused_topk = false;
+      int n_cand = 0;
       if (!split) {
         GemmArgs g;
         g.X = qn.f; g.ldx = LBM_C; g.sX = (long long)d->N * LBM_C;
@@ -376,7 +380,18 @@ struct Step {
       } else {
         // F holds, per layer, the hi planes of all streams followed by their lo planes
         const long long plane = (long long)d->B * lay.P0 * LBM_C;
+        // nobody asked for the correlation map itself: let the product keep only each 128-column tile's k best per row
+        // (in the space the map would have taken) and select among those -- the R x P0 map is neither written nor re-read
+        // (measured: the 9-deep per-lane lists cost the tile epilogue ~25 us at 1024 rows, more than the map's round trip
+        // saves there; from ~4000 rows on the product is throughput-bound and the fusion wins 4 % of the C5 step)
+        fused_topk = d->corr[i] == nullptr && gemm_ss_topk_ok(gm, (int)lay.P0, LBM_C, gb, k) && (k <= g_fuse_kmax_small || Rfull >= 4096);
         GemmSSArgs g;
+        if (fused_topk) {
+          n_cand = (int)((lay.P0 + 127) / 128) * k;
+          g.cand_v = cdst;
+          g.cand_i = reinterpret_cast<int*>(cdst + (long long)R * n_cand);
+          g.topk_k = k;
+        }
         g.A = qn.s; g.a_plane = qn.plane; g.lda = LBM_C; g.sA = (long long)d->N * LBM_C;
         g.B = (const char*)F + (long long)i * plane * 4; g.b_plane = plane; g.ldb = LBM_C; g.sB = lay.P0 * LBM_C;
         g.Y = cdst; g.ldy = (int)lay.P0; g.sY = (long long)d->N * lay.P0;
@@ -385,7 +400,13 @@ struct Step {
       }
       int* idst = d->topk_idx[i] ? d->topk_idx[i] + (long long)lo * k : idx;
       float* rdst = d->ref_points[i] ? d->ref_points[i] + (long long)lo * k * 2 : ref;
-      if (topk_rows(cdst, lay.P0, (int)lay.P0, k, R, w, d->stride, idst, rdst, nullptr, s)) return -1;
+      if (fused_topk) {
+        if (topk_candidates(cdst, reinterpret_cast<const int*>(cdst + (long long)R * n_cand), n_cand, (int)lay.P0, k, R, w, d->stride, idst,
+                            rdst, nullptr, s))
+          return -1;
+      } else if (topk_rows(cdst, lay.P0, (int)lay.P0, k, R, w, d->stride, idst, rdst, nullptr, s)) {
+        return -1;
+      }
       // lattice deformable attention on the k regions (transformer.py:316-327)
       if (msda_block(lw + LBM_W_LAYER_LATTICE, i, d->n_points, tb, rdst, k, lb)) return -1;
       if (d->ref_rho[i]) {   // [1,256] read-out, kept on the exact fp32 path in both modes (weights stay fp32)
@@ -570,6 +591,10 @@ int lbm_hip_debug_set(int32_t key, int32_t value) {
   }
   if (key == 5) {
     topk_force_mode(value);
+    return 0;
+  }
+  if (key == 6) {
+    g_fuse_kmax_small = value;
     return 0;
   }
   set_error("debug_set: unknown key %d", key);

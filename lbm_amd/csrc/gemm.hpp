@@ -70,8 +70,15 @@ struct GemmSSArgs {
   int act = ACT_NONE;
   int batch = 1;
   long long sA = 0, sB = 0, sBias = 0, sY = 0, sYs = 0, sR = 0;
+  // Optional fused row-wise top-k pre-selection (the correlation product): instead of Y, every 128-column tile leaves the
+  // topk_k best (value, column) pairs of each of its rows in cand_v / cand_i [batch * M, ceil(N / 128) * topk_k], ties to
+  // the lower column; the union holds the exact top-k of the row.  Needs the 128 x 128 tiling (gemm_ss_topk_ok).
+  float* cand_v = nullptr;
+  int* cand_i = nullptr;
+  int topk_k = 0;
 };
 int gemm_ss(const GemmSSArgs& a, hipStream_t stream);
+bool gemm_ss_topk_ok(int M, int N, int K, int batch, int k);   // would gemm_ss take the fused top-k path for this shape?
 
 // NHWC convolution with split operands staged by LDS-DMA gather (Cin a power of two >= 32).
 struct ConvSSArgs {

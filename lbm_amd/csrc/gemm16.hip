@@ -401,6 +401,9 @@ struct GemmSSDev {
   int cH, cW, cin_log2, ckw, cstride, cpad, cHo, cWo;
   const void* zeros;
   int kt0_per_z;   // K-split over gridDim.z for convolutions: block z starts at chunk z * kt0_per_z
+  float* cand_v;   // TOPK epilogue: per-tile candidates [batch * M, ntile_n * topk_k] (values / global columns)
+  int* cand_i;
+  int topk_k;
   int vec_ok;      // outputs / residual admit 16-byte row pieces (N, leading dimensions, strides multiples of 4; aligned bases)
 };
 
@@ -484,7 +487,7 @@ __device__ __forceinline__ void pf_steps(F& f) {
 // FULL: K / 32 == STAGES exactly; the DMA of the whole K extent is issued up front (STAGES x stage bytes of LDS, one
 // workgroup per CU).  This is the small-problem variant: with ~1 workgroup per CU nothing else hides the DMA
 // latency, so it is paid once per workgroup instead of once per chunk.
-template <int BM, int BN, int WM, int WN, int STAGES, bool CONV, bool FULL = false>
+template <int BM, int BN, int WM, int WN, int STAGES, bool CONV, bool FULL = false, int TOPK = 0>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_ss_kernel(GemmSSDev a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // LDS-DMA builtins and s_waitcnt asm exist on the device side only
   constexpr int NW = WM * WN;
@@ -685,6 +688,76 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_ss_kernel(GemmSSDev a) {
       }
     }
     __syncthreads();
+    if constexpr (TOPK > 0) {
+      // Row-wise top-k pre-selection on the staged tile: 4 adjacent lanes share a row (NW * 64 == 4 * BM), lane `sub` walks
+      // columns sub, sub + 4, ... (conflict-free: 16 rows x 4 lanes cover the 64 banks) keeping a sorted list of its
+      // topk_k best in registers; the four lists are merged by topk_k rounds of a 4-lane arg-max and lane 0 writes the
+      // pair.  The 64 KB tile itself never leaves the CU.
+      static_assert(NW * 64 == 4 * BM, "TOPK epilogue: four lanes per tile row");
+      constexpr int KM = TOPK;                      // list depth: the smallest of 1 / 4 / 9 that holds topk_k
+      const int rl = tid >> 2, sub = tid & 3;
+      const int row = m0 + rl;
+      const int kk = a.topk_k;
+      float lv[KM];
+      int li[KM];
+#pragma unroll
+      for (int t = 0; t < KM; ++t) {
+        lv[t] = -INFINITY;
+        li[t] = 0x7fffffff;
+      }
+      // lane `sub` owns the 32 consecutive columns [32 sub, 32 sub + 32) of its row, read as eight 16-byte pieces
+      const float* Tr = T + rl * TP + sub * (BN / 4);
+#pragma unroll
+      for (int i4 = 0; i4 < BN / 16; ++i4) {
+        const float4 q = *reinterpret_cast<const float4*>(Tr + i4 * 4);
+        const float qv[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c = sub * (BN / 4) + i4 * 4 + e;
+          const float v = qv[e];
+          if (n0 + c < a.N && v > lv[KM - 1]) {        // columns ascend: a tie never displaces an earlier column
+            lv[KM - 1] = v;
+            li[KM - 1] = n0 + c;
+#pragma unroll
+            for (int t = KM - 1; t > 0; --t) {
+              if (lv[t] > lv[t - 1]) {                   // strict: equal values keep column order
+                const float tv = lv[t]; lv[t] = lv[t - 1]; lv[t - 1] = tv;
+                const int ti = li[t]; li[t] = li[t - 1]; li[t - 1] = ti;
+              }
+            }
+          }
+        }
+      }
+      const long long ntile = (a.N + BN - 1) / BN;
+      const long long co = ((long long)z * a.M + row) * ntile * kk + (long long)blockIdx.x * kk;
+      for (int t = 0; t < kk; ++t) {
+        float bv = lv[0];
+        int bi = li[0];
+#pragma unroll
+        for (int sft = 1; sft < 4; sft <<= 1) {
+          const float ov = __shfl_xor(bv, sft);
+          const int oi = __shfl_xor(bi, sft);
+          if (ov > bv || (ov == bv && oi < bi)) {
+            bv = ov;
+            bi = oi;
+          }
+        }
+        if (li[0] == bi && bi != 0x7fffffff) {          // the winner pops its head
+#pragma unroll
+          for (int q = 0; q < KM - 1; ++q) {
+            lv[q] = lv[q + 1];
+            li[q] = li[q + 1];
+          }
+          lv[KM - 1] = -INFINITY;
+          li[KM - 1] = 0x7fffffff;
+        }
+        if (sub == 0 && row < a.M) {
+          a.cand_v[co + t] = bv;
+          a.cand_i[co + t] = bi;
+        }
+      }
+      return;
+    }
     constexpr int C4 = BN / 4;
     for (int c = tid; c < BM * C4; c += NW * 64) {
       const int rl = c / C4, c4 = c - rl * C4;
@@ -739,10 +812,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_ss_kernel(GemmSSDev a) {
 #endif
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, bool CONV = false, bool FULL = false>
+template <int BM, int BN, int WM, int WN, int STAGES, bool CONV = false, bool FULL = false, int TOPK = 0>
 static int launch_ss(const GemmSSDev& d, int batch, hipStream_t stream) {
   dim3 grid((d.N + BN - 1) / BN, (d.M + BM - 1) / BM, batch);
-  static const std::string name = std::string(CONV ? "conv_ss" : "gemm_ss") + (FULL ? "_full<" : "<") + std::to_string(BM) + "," + std::to_string(BN) + "," + std::to_string(WM) +
+  static const std::string name = std::string(CONV ? "conv_ss" : TOPK ? "gemm_ss_topk" + std::to_string(TOPK) : "gemm_ss") + (FULL ? "_full<" : "<") + std::to_string(BM) + "," + std::to_string(BN) + "," + std::to_string(WM) +
                                   "," + std::to_string(WN) + "," + std::to_string(STAGES) + ">";
   const double mnk = (double)d.M * d.N * d.K * batch;
   GemmSSDev dv = d;
@@ -750,7 +823,7 @@ static int launch_ss(const GemmSSDev& d, int batch, hipStream_t stream) {
   ProfScope prof(name.c_str(), stream, 2.0 * mnk,
                  4.0 * ((double)d.M * d.K * batch + (double)d.N * d.K * (d.sB || batch == 1 ? batch : 1) +
                         (double)d.M * d.N * batch * ((d.Y ? 1 : 0) + (d.Ys ? 1 : 0) + (d.res ? 1 : 0))));
-  hipLaunchKernelGGL((gemm_ss_kernel<BM, BN, WM, WN, STAGES, CONV, FULL>), grid, dim3(WM * WN * 64), 0, stream, dv);
+  hipLaunchKernelGGL((gemm_ss_kernel<BM, BN, WM, WN, STAGES, CONV, FULL, TOPK>), grid, dim3(WM * WN * 64), 0, stream, dv);
   return check_launch(CONV ? "conv_ss" : "gemm_ss");
 }
 
@@ -877,10 +950,16 @@ int conv2d_nhwc_ss(const ConvSSArgs& c, hipStream_t stream) {
   return check_launch("slab_reduce");
 }
 
+bool gemm_ss_topk_ok(int M, int N, int K, int batch, int k) {
+  // the shapes for which the plain product would run the 128 x 128 tiling anyway
+  const long long big = (long long)((M + 127) / 128) * ((N + 127) / 128) * batch;
+  return k >= 1 && k <= 9 && N % 4 == 0 && N > 64 && big >= 128 && ((long long)((N + 127) / 128) * k) % 4 == 0 && !(g_dbg16 & 128);
+}
+
 int gemm_ss(const GemmSSArgs& a, hipStream_t stream) {
   LBM_REQUIRE(a.M >= 0 && a.N > 0 && a.K > 0, "gemm_ss: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
   if (a.M == 0) return 0;
-  LBM_REQUIRE(a.A && a.B && (a.Y || a.Ys), "gemm_ss: null operand");
+  LBM_REQUIRE(a.A && a.B && (a.Y || a.Ys || a.topk_k > 0), "gemm_ss: null operand");
   LBM_REQUIRE(a.K % 32 == 0, "gemm_ss: K=%d must be a multiple of 32", a.K);
   LBM_REQUIRE(a.lda % 8 == 0 && a.ldb % 8 == 0 && a.lda >= a.K && a.ldb >= a.K, "gemm_ss: lda=%d / ldb=%d must be multiples of 8 and >= K", a.lda, a.ldb);
   LBM_REQUIRE(a.a_plane % 8 == 0 && a.b_plane % 8 == 0 && a.sA % 8 == 0 && a.sB % 8 == 0, "gemm_ss: plane / batch strides must keep 16-byte alignment");
@@ -896,6 +975,14 @@ int gemm_ss(const GemmSSArgs& a, hipStream_t stream) {
   d.res_div = a.res_div; d.res_mod = a.res_mod; d.res_scale = a.res_scale; d.act = a.act;
   d.sA = a.sA; d.sB = a.sB; d.sBias = a.sBias; d.sY = a.sY; d.sYs = a.sYs; d.sR = a.sR;
   d.dbg = g_dbg16;
+  if (a.topk_k > 0) {
+    LBM_REQUIRE(a.cand_v && a.cand_i && gemm_ss_topk_ok(a.M, a.N, a.K, a.batch, a.topk_k) && !a.bias && !a.res && a.act == ACT_NONE,
+                "gemm_ss: fused top-k needs candidate buffers, k <= 9, N %% 4 == 0 and a plain product");
+    d.cand_v = a.cand_v; d.cand_i = a.cand_i; d.topk_k = a.topk_k; d.Y = nullptr; d.Ys = nullptr;
+    if (a.topk_k == 1) return launch_ss<128, 128, 2, 4, 2, false, false, 1>(d, a.batch, stream);
+    if (a.topk_k <= 4) return launch_ss<128, 128, 2, 4, 2, false, false, 4>(d, a.batch, stream);
+    return launch_ss<128, 128, 2, 4, 2, false, false, 9>(d, a.batch, stream);
+  }
   const long long big = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.batch;
   int t = g_force_tile16;
   const long long mid = (long long)((a.M + 63) / 64) * ((a.N + 63) / 64) * a.batch;

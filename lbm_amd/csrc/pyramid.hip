@@ -363,10 +363,13 @@ __device__ __forceinline__ unsigned topk_key(float v) {
 }
 __device__ __forceinline__ float topk_unkey(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
 
-template <int NV>
+// CAND: the row is a list of (value, column) candidates (the per-tile pre-selection of the fused correlation product,
+// gemm16.hip) instead of a dense row; columns then come from cand_i and run up to idx_max.
+template <int NV, bool CAND>
 __global__ __launch_bounds__(256) void topk_rows_wide_kernel(const float* __restrict__ corr, long long ld, int P, int k, int rows,
                                                             int grid_w, float cell, int* __restrict__ idx_out,
-                                                            float* __restrict__ ref_out, float* __restrict__ val_out) {
+                                                            float* __restrict__ ref_out, float* __restrict__ val_out,
+                                                            const int* __restrict__ cand_i, int idx_max) {
   constexpr int CAP = 1024;
   __shared__ float s_tau[4];
   __shared__ float s_red[2][4];
@@ -380,13 +383,21 @@ __global__ __launch_bounds__(256) void topk_rows_wide_kernel(const float* __rest
   const int nvec = P >> 2;
   const float* src = corr + (long long)row * ld;
   float4 buf[NV];
+  int4 ibuf[CAND ? NV : 1];
   float mx = -INFINITY;
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     const int f = tid + j * 256;
     buf[j] = f < nvec ? ld4(src + f * 4) : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    if (CAND)
+      ibuf[j] = f < nvec ? *reinterpret_cast<const int4*>(cand_i + (long long)row * ld + f * 4)
+                         : make_int4(0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff);
     mx = fmaxf(fmaxf(mx, fmaxf(buf[j].x, buf[j].y)), fmaxf(buf[j].z, buf[j].w));
   }
+  auto idx_of = [&](int j, int c) {
+    if (CAND) return c == 0 ? ibuf[j].x : c == 1 ? ibuf[j].y : c == 2 ? ibuf[j].z : ibuf[j].w;
+    return (tid + j * 256) * 4 + c;
+  };
   const float rmax_w = wave_max(mx);
   float tau = -INFINITY;
   for (int t = 0; t < k; ++t) {        // k rounds: wave max, then the (first) lane holding it drops out
@@ -414,11 +425,10 @@ __global__ __launch_bounds__(256) void topk_rows_wide_kernel(const float* __rest
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     if (fmaxf(fmaxf(buf[j].x, buf[j].y), fmaxf(buf[j].z, buf[j].w)) >= tau) {
-      const int i0 = (tid + j * 256) * 4;
-      push(buf[j].x, i0);
-      push(buf[j].y, i0 + 1);
-      push(buf[j].z, i0 + 2);
-      push(buf[j].w, i0 + 3);
+      push(buf[j].x, idx_of(j, 0));
+      push(buf[j].y, idx_of(j, 1));
+      push(buf[j].z, idx_of(j, 2));
+      push(buf[j].w, idx_of(j, 3));
     }
   }
   __syncthreads();
@@ -490,7 +500,7 @@ __global__ __launch_bounds__(256) void topk_rows_wide_kernel(const float* __rest
     }
     const unsigned T = lo;
     const int need = k - (T == 0xffffffffu ? 0 : count_ge(T + 1));     // how many of the elements equal to T are taken
-    int jlo = 0, jhi = P - 1;
+    int jlo = 0, jhi = CAND ? idx_max : P - 1;
     while (jlo < jhi) {
       const int jm = (jlo + jhi) >> 1;
       int c = 0;
@@ -529,12 +539,11 @@ __global__ __launch_bounds__(256) void topk_rows_wide_kernel(const float* __rest
     int ie[NV * 4];
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-      const int i0 = (tid + j * 256) * 4;
-      const bool in = i0 < P;
-      ke[4 * j + 0] = in ? topk_key(buf[j].x) : 0u; ie[4 * j + 0] = in ? i0 : 0x7fffffff;
-      ke[4 * j + 1] = in ? topk_key(buf[j].y) : 0u; ie[4 * j + 1] = in ? i0 + 1 : 0x7fffffff;
-      ke[4 * j + 2] = in ? topk_key(buf[j].z) : 0u; ie[4 * j + 2] = in ? i0 + 2 : 0x7fffffff;
-      ke[4 * j + 3] = in ? topk_key(buf[j].w) : 0u; ie[4 * j + 3] = in ? i0 + 3 : 0x7fffffff;
+      const bool in = (tid + j * 256) * 4 < P;
+      ke[4 * j + 0] = in ? topk_key(buf[j].x) : 0u; ie[4 * j + 0] = in ? idx_of(j, 0) : 0x7fffffff;
+      ke[4 * j + 1] = in ? topk_key(buf[j].y) : 0u; ie[4 * j + 1] = in ? idx_of(j, 1) : 0x7fffffff;
+      ke[4 * j + 2] = in ? topk_key(buf[j].z) : 0u; ie[4 * j + 2] = in ? idx_of(j, 2) : 0x7fffffff;
+      ke[4 * j + 3] = in ? topk_key(buf[j].w) : 0u; ie[4 * j + 3] = in ? idx_of(j, 3) : 0x7fffffff;
     }
     select(ke, ie);
   }
@@ -565,11 +574,11 @@ int topk_rows(const float* corr, long long ld, int P, int k, int rows, int grid_
                  4.0 * rows * ((double)P + 4.0 * k));
   if (wide && P % 4 == 0 && P <= 16 * 1024 && g_topk_mode == 0) {   // the row fits the registers of one workgroup
     if (P <= 4 * 1024)
-      hipLaunchKernelGGL((topk_rows_wide_kernel<4>), grid, dim3(256), 0, stream, corr, ld, P, k, rows, grid_w, cell, idx_out, ref_out, val_out);
+      hipLaunchKernelGGL((topk_rows_wide_kernel<4, false>), grid, dim3(256), 0, stream, corr, ld, P, k, rows, grid_w, cell, idx_out, ref_out, val_out, nullptr, 0);
     else if (P <= 12 * 1024)
-      hipLaunchKernelGGL((topk_rows_wide_kernel<12>), grid, dim3(256), 0, stream, corr, ld, P, k, rows, grid_w, cell, idx_out, ref_out, val_out);
+      hipLaunchKernelGGL((topk_rows_wide_kernel<12, false>), grid, dim3(256), 0, stream, corr, ld, P, k, rows, grid_w, cell, idx_out, ref_out, val_out, nullptr, 0);
     else
-      hipLaunchKernelGGL((topk_rows_wide_kernel<16>), grid, dim3(256), 0, stream, corr, ld, P, k, rows, grid_w, cell, idx_out, ref_out, val_out);
+      hipLaunchKernelGGL((topk_rows_wide_kernel<16, false>), grid, dim3(256), 0, stream, corr, ld, P, k, rows, grid_w, cell, idx_out, ref_out, val_out, nullptr, 0);
     return check_launch("topk_rows");
   }
   if (k == 1) launch_topk<1>(wide, grid, stream, corr, ld, P, k, rows, grid_w, cell, idx_out, ref_out, val_out);
@@ -577,6 +586,25 @@ int topk_rows(const float* corr, long long ld, int P, int k, int rows, int grid_
   else if (k <= 9) launch_topk<9>(wide, grid, stream, corr, ld, P, k, rows, grid_w, cell, idx_out, ref_out, val_out);
   else launch_topk<16>(wide, grid, stream, corr, ld, P, k, rows, grid_w, cell, idx_out, ref_out, val_out);
   return check_launch("topk_rows");
+}
+
+// Final selection over the per-tile candidates of the fused correlation product: rows of n_cand (value, column) pairs.
+int topk_candidates(const float* cand_v, const int* cand_i, int n_cand, int P, int k, int rows, int grid_w, int stride_px, int* idx_out,
+                    float* ref_out, float* val_out, hipStream_t stream) {
+  if (rows == 0) return 0;
+  LBM_REQUIRE(cand_v && cand_i && idx_out, "topk_candidates: null argument");
+  LBM_REQUIRE(k >= 1 && k <= 16 && k <= n_cand && n_cand % 4 == 0 && n_cand <= 4096, "topk_candidates: k=%d, n_cand=%d out of range", k, n_cand);
+  LBM_REQUIRE(((uintptr_t)cand_v & 15) == 0 && ((uintptr_t)cand_i & 15) == 0, "topk_candidates: rows must be 16-byte aligned");
+  const float cell = (float)stride_px;
+  ProfScope prof(k == 1 ? "topk_cand_k1" : k <= 4 ? "topk_cand_k4" : "topk_cand_k9", stream, 0.0, 8.0 * rows * ((double)n_cand + k));
+  const dim3 grid(rows);
+  if (n_cand <= 1024)
+    hipLaunchKernelGGL((topk_rows_wide_kernel<1, true>), grid, dim3(256), 0, stream, cand_v, (long long)n_cand, n_cand, k, rows, grid_w, cell,
+                       idx_out, ref_out, val_out, cand_i, P - 1);
+  else
+    hipLaunchKernelGGL((topk_rows_wide_kernel<4, true>), grid, dim3(256), 0, stream, cand_v, (long long)n_cand, n_cand, k, rows, grid_w, cell,
+                       idx_out, ref_out, val_out, cand_i, P - 1);
+  return check_launch("topk_candidates");
 }
 
 }  // namespace lbm

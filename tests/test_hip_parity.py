@@ -585,3 +585,26 @@ def test_frame_pipeline_gives_the_same_tracks_as_serial_frames(hip):
             assert torch.equal(x, y)
     for i in (1, 2, 3):
         assert torch.equal(runs["serial"][i], runs["pipelined"][i])
+
+
+def test_correlation_product_with_fused_top_k_selects_the_same_cells(hip):
+    """The correlation GEMM that keeps only each 128-column tile's k best per row (taken for k = 9 / 4 from 4096 rows on)
+    against the unfused product + dense top-k, on the same inputs: the selected cells of every layer, and with them every
+    output, must be identical."""
+    g = fx.geometry("full256")
+    tr, _ = _transformer(g, precision="split")
+    cu = {k: v.cuda() for k, v in fx.step_inputs(g, 2, 300, seed=78).items()}
+    lib = hip.load()
+    outs = {}
+    try:
+        for mode in (9, 0):
+            lib.lbm_hip_debug_set(6, mode)
+            with torch.no_grad():
+                outs[mode] = tr(cu["query"], cu["feat"], cu["stream"], cu["collision"], cu["vis_mask"], cu["mem_mask"], cu["queried"])
+    finally:
+        lib.lbm_hip_debug_set(6, 1)
+    a, b = outs[9], outs[0]
+    for la, lb in zip(a[0], b[0]):
+        assert torch.equal(la["reference_points"], lb["reference_points"])
+    for i in (2, 3, 4):
+        assert torch.equal(a[i], b[i])

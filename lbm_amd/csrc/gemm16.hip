@@ -395,7 +395,7 @@ struct GemmSSDev {
   float res_scale;
   int act;
   long long sA, sB, sBias, sY, sYs, sR;   // batch strides (elements)
-  int dbg;   // ablation switches (tuning only): 1 = no DMA after the prologue (FULL: none at all), 2 = no MFMA, 4 = no output stores, 8 = return at once, 16 = direct epilogue
+  int dbg;   // ablation switches (tuning only): 1 = no DMA after the prologue (FULL: none at all), 4 = no output stores, 8 = return at once, 16 = direct epilogue
   // implicit-GEMM convolution (CONV): A is an NHWC activation as split planes [B, cH, cW, Cin], Cin a multiple of 32;
   // row m = (b, oy, ox), column k = (ky, kx, ci).  Taps outside the image read `zeros` (>= 16 zero bytes).
   int cH, cW, cin_log2, ckw, cstride, cpad, cHo, cWo;
@@ -601,40 +601,38 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_ss_kernel(GemmSSDev a) {
     for (int s = 0; s < 2; ++s) offB[j][s] = row * 64 + (((2 * s + h) ^ ((row >> 2) & 3)) << 4);
   }
 
+  // All fragments of the chunk (both 16-deep steps) are requested before the first MFMA, so the second step's LDS
+  // reads are in flight under the first step's MFMAs (the compiler counts lgkmcnt per use).  No run-time switches in
+  // here: a scalar branch between the reads and the MFMAs stops that overlap (seen in the ISA of the first version).
   auto compute = [&](int stage) {
     const unsigned char* Ah = lds + stage * STAGE;
     const unsigned char* Al = Ah + PLANE_A;
     const unsigned char* Bh = Al + PLANE_A;
     const unsigned char* Bl = Bh + PLANE_B;
+    half8 fah[2][TM], fal[2][TM], fbh[2][TN], fbl[2][TN];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      half8 fah[TM], fal[TM], fbh[TN], fbl[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        fah[i] = *reinterpret_cast<const half8*>(Ah + offA[i][s]);
-        fal[i] = *reinterpret_cast<const half8*>(Al + offA[i][s]);
+        fah[s][i] = *reinterpret_cast<const half8*>(Ah + offA[i][s]);
+        fal[s][i] = *reinterpret_cast<const half8*>(Al + offA[i][s]);
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        fbh[j] = *reinterpret_cast<const half8*>(Bh + offB[j][s]);
-        fbl[j] = *reinterpret_cast<const half8*>(Bl + offB[j][s]);
-      }
-      if (a.dbg & 2) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(fah[i]), "v"(fal[i]));
-#pragma unroll
-        for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(fbh[j]), "v"(fbl[j]));
-      } else {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[i], fbh[j], acc[i][j], 0, 0, 0);
-            acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[i], fbl[j], acx[i][j], 0, 0, 0);
-            acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[i], fbh[j], acx[i][j], 0, 0, 0);
-          }
+        fbh[s][j] = *reinterpret_cast<const half8*>(Bh + offB[j][s]);
+        fbl[s][j] = *reinterpret_cast<const half8*>(Bl + offB[j][s]);
       }
     }
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[s][i], fbh[s][j], acc[i][j], 0, 0, 0);
+          acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[s][i], fbl[s][j], acx[i][j], 0, 0, 0);
+          acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[s][i], fbh[s][j], acx[i][j], 0, 0, 0);
+        }
   };
   if constexpr (FULL) {
     pf_steps<0, STAGES, PPW>(compute);

@@ -19,6 +19,8 @@
 #include "gemm.hpp"
 #include "rows.hpp"
 
+#include <cstdlib>
+#include <set>
 #include <string>
 
 namespace lbm {
@@ -816,9 +818,14 @@ static int launch_ss(const GemmSSDev& d, int batch, hipStream_t stream) {
   static const std::string name = std::string(CONV ? "conv_ss" : TOPK ? "gemm_ss_topk" + std::to_string(TOPK) : "gemm_ss") + (FULL ? "_full<" : "<") + std::to_string(BM) + "," + std::to_string(BN) + "," + std::to_string(WM) +
                                   "," + std::to_string(WN) + "," + std::to_string(STAGES) + ">";
   const double mnk = (double)d.M * d.N * d.K * batch;
+  static const bool by_shape = getenv("LBM_PROF_SHAPES") != nullptr;      // profiling aid: one entry per problem shape
+  static std::set<std::string> interned;                                  // stable storage for the names handed to ProfScope
+  std::string shaped;
+  if (by_shape) shaped = name + " " + std::to_string(d.M) + "x" + std::to_string(d.N) + "x" + std::to_string(d.K) + "x" + std::to_string(batch) +
+                         (d.Y ? " f32" : "") + (d.Ys ? " split" : "");
   GemmSSDev dv = d;
   dv.vec_ok = vec_ok_of(d);
-  ProfScope prof(name.c_str(), stream, 2.0 * mnk,
+  ProfScope prof(by_shape ? interned.insert(shaped).first->c_str() : name.c_str(), stream, 2.0 * mnk,
                  4.0 * ((double)d.M * d.K * batch + (double)d.N * d.K * (d.sB || batch == 1 ? batch : 1) +
                         (double)d.M * d.N * batch * ((d.Y ? 1 : 0) + (d.Ys ? 1 : 0) + (d.res ? 1 : 0))));
   hipLaunchKernelGGL((gemm_ss_kernel<BM, BN, WM, WN, STAGES, CONV, FULL, TOPK>), grid, dim3(WM * WN * 64), 0, stream, dv);

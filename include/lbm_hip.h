@@ -64,6 +64,7 @@ typedef struct {
   float res_scale;
   int32_t act, batch;
   int64_t sA, sB, sBias, sY, sYs, sR;
+  int32_t planes;   /* 0 or 2: hi and lo planes multiplied (fp32-grade); 1: hi planes only (plain f16 operands) */
 } lbm_hip_linear_ss_desc;
 int lbm_hip_linear_ss(const lbm_hip_linear_ss_desc* d, lbm_stream_t stream);
 
@@ -148,6 +149,7 @@ int lbm_hip_maxpool3x3s2_nhwc(const float* x, float* y, int32_t B, int32_t H, in
  * conv2d_nhwc_ss: activation X [B,H,W,Cin] (Cin a power of two >= 32) and packed weights both split; im2col rows are
  *   gathered straight into LDS by DMA, out-of-image taps read `zeros` (>= 16 zero bytes of device memory).  Output as
  *   fp32 (Y) and/or split (Ys).  `scratch` (optional, fp32) lets small problems split K over more workgroups.
+ *   W_lo == NULL: only the hi planes of X and W are multiplied (reduced precision, as step precision 2).
  * maxpool / upcat / pyramid *_s variants additionally (or only) emit the split twin of their output.             */
 int lbm_hip_conv2d_nhwc_ss(const void* X, int64_t x_plane, const void* W_hi, const void* W_lo, const float* bias,
                            const float* res, float* Y, void* Ys, int64_t ys_plane, const void* zeros, void* scratch,
@@ -237,7 +239,11 @@ typedef struct {
   /* precision 0: every contraction on the exact-fp32 MFMA (weights[] are fp32 matrices).
    * precision 1: contractions on the f16 matrix cores with split operands (fp32-grade, see lbm_hip_split_planes):
    *   for every MATRIX entry of the table, weights[i] is its f16 hi plane and weights_lo[i] its f16 lo plane;
-   *   vectors (biases, LayerNorm, time embeddings) and LBM_W_LAYER_RHO_W stay fp32 in weights[].                */
+   *   vectors (biases, LayerNorm, time embeddings) and LBM_W_LAYER_RHO_W stay fp32 in weights[].
+   * precision 2: the reduced-precision mode ("bf16 storage with fp32 accumulate", bar 1e-2 on logits): the
+   *   same kernels multiply the f16 hi planes only (plain f16 operands, 11 significant bits -- 3 more than bf16 --
+   *   one MFMA per block, half the operand staging); weights_lo may be NULL.  Everything that is not a dense
+   *   contraction stays fp32.                                                                                     */
   int32_t precision;
   const void* const* weights_lo;
   /* inputs */

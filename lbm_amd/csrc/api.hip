@@ -90,7 +90,7 @@ static int build_layout(const lbm_hip_step_desc* d, StepLayout& lay) {
   LBM_REQUIRE(d != nullptr, "step: null descriptor");
   LBM_REQUIRE(d->B >= 1 && d->N >= 0 && d->M >= 1 && d->M <= 4096, "step: bad B/N/M (%d, %d, %d)", d->B, d->N, d->M);
   LBM_REQUIRE(d->n_layers >= 1 && d->n_layers <= LBM_HIP_MAX_LAYERS, "step: n_layers=%d out of range", d->n_layers);
-  LBM_REQUIRE(d->precision == 0 || d->precision == 1, "step: precision must be 0 (fp32 MFMA) or 1 (split f16 MFMA)");
+  LBM_REQUIRE(d->precision >= 0 && d->precision <= 2, "step: precision must be 0 (fp32 MFMA), 1 (split f16 MFMA) or 2 (plain f16 MFMA)");
   LBM_REQUIRE(d->stride == 4 && d->net_h % 32 == 0 && d->net_w % 32 == 0 && d->net_h > 0 && d->net_w > 0,
               "step: network input %dx%d (stride %d) must be a multiple of 32 with stride 4", d->net_h, d->net_w, d->stride);
   int kmax = 1;
@@ -132,7 +132,7 @@ static int build_layout(const lbm_hip_step_desc* d, StepLayout& lay) {
   lay.add("preq", (unsigned long long)lay.Q * LBM_C * f);                   // pre-LayerNorm rows
   lay.add("slab", 4ull * Step_kSlabRows * LBM_C * f);                       // K-split partial products, one region per sub-run
   lay.add("hidR", (unsigned long long)lay.R * LBM_C * f);
-  if (d->precision == 1) {   // split twins (two f16 planes = the same number of bytes as the fp32 tensor)
+  if (d->precision >= 1) {   // split twins (two f16 planes = the same number of bytes as the fp32 tensor)
     if (d->tokens_split == nullptr) lay.add("tok_s", (unsigned long long)d->B * lay.L * LBM_C * f);
     lay.add("q_s", (unsigned long long)lay.R * LBM_C * f);
     lay.add("x0_s", (unsigned long long)lay.R * LBM_C * f);
@@ -161,7 +161,8 @@ struct Step {
   hipStream_t s;
   char* ws;
   int h, w;
-  bool split;      // precision 1: dense contractions on the f16 matrix cores with split operands
+  bool split;      // precision 1 / 2: dense contractions on the f16 matrix cores with split operands
+  int planes = 2;  // 2: hi and lo planes multiplied (fp32-grade); 1: hi planes only (precision 2, reduced)
   // Points never interact, so the per-point phase can run on any partition of the rows: this run covers
   // rows [lo, lo + R) of Rfull; `sub` of `nsub` names its private K-split slab region.
   long long Rfull = 0;
@@ -173,6 +174,10 @@ struct Step {
     return reinterpret_cast<T*>(ws + lay.find(name));
   }
   const float* W(int idx) const { return d->weights[idx]; }
+  // distance (f16 elements) from the hi plane of matrix idx to its lo plane; unused when only hi planes are multiplied
+  long long lo_plane(int idx) const {
+    return planes == 2 ? ((const char*)d->weights_lo[idx] - (const char*)d->weights[idx]) / 2 : 0;
+  }
   // rows-of-points buffers with capacity `cap` rows of width `wd` per point; this run owns the byte range of its
   // own points (so concurrent runs never touch each other's scratch, whatever `mult` <= cap each is using right
   // now) and lays `mult` rows per point out inside it.  fname: fp32 buffer; sname: split twin, hi plane at the start
@@ -202,8 +207,9 @@ struct Step {
       return gemm(a, s);
     }
     GemmSSArgs a;
+    a.planes = planes;
     a.A = X.s; a.a_plane = X.plane; a.lda = ldx;
-    a.B = d->weights[wi]; a.b_plane = ((const char*)d->weights_lo[wi] - (const char*)d->weights[wi]) / 2;
+    a.B = d->weights[wi]; a.b_plane = lo_plane(wi);
     a.ldb = K; a.bias = bi >= 0 ? W(bi) : nullptr;
     a.Y = Y.f; a.ldy = ldy; a.Ys = Y.s; a.ys_plane = Y.plane; a.ldys = ldy;
     a.M = M; a.N = N; a.K = K; a.act = act; a.res = res; a.ldres = LBM_C; a.res_div = res_div; a.res_scale = res_scale;
@@ -232,8 +238,9 @@ struct Step {
         nsplit *= 2;
       if (nsplit > 1) pre = buf<float>("slab") + (long long)sub * kSlabRows * LBM_C;
       GemmSSArgs a;
+      a.planes = planes;
       a.A = X.s; a.a_plane = X.plane; a.lda = ldx;
-      a.B = d->weights[wi]; a.b_plane = ((const char*)d->weights_lo[wi] - (const char*)d->weights[wi]) / 2; a.ldb = K;
+      a.B = d->weights[wi]; a.b_plane = lo_plane(wi); a.ldb = K;
       a.Y = pre; a.ldy = LBM_C; a.M = M; a.N = LBM_C; a.K = K / nsplit;
       a.batch = nsplit; a.sA = K / nsplit; a.sB = K / nsplit; a.sY = (long long)M * LBM_C;
       if (gemm_ss(a, s)) return -1;
@@ -384,8 +391,10 @@ struct Step {
         // (in the space the map would have taken) and select among those -- the R x P0 map is neither written nor re-read
         // (measured: the 9-deep per-lane lists cost the tile epilogue ~25 us at 1024 rows, more than the map's round trip
         // saves there; from ~4000 rows on the product is throughput-bound and the fusion wins 4 % of the C5 step)
-        fused_topk = d->corr[i] == nullptr && gemm_ss_topk_ok(gm, (int)lay.P0, LBM_C, gb, k) && (k <= g_fuse_kmax_small || Rfull >= 4096);
+        fused_topk = planes == 2 && d->corr[i] == nullptr && gemm_ss_topk_ok(gm, (int)lay.P0, LBM_C, gb, k) &&
+                     (k <= g_fuse_kmax_small || Rfull >= 4096);
         GemmSSArgs g;
+        g.planes = planes;
         if (fused_topk) {
           n_cand = (int)((lay.P0 + 127) / 128) * k;
           g.cand_v = cdst;
@@ -490,6 +499,7 @@ int lbm_hip_linear_ss(const lbm_hip_linear_ss_desc* d, lbm_stream_t stream) {
   a.ldys = d->ldys; a.ldres = d->ldres; a.res_div = d->res_div > 0 ? d->res_div : 1;
   a.res_mod = d->res_mod > 0 ? d->res_mod : 0x7fffffff; a.res_scale = d->res_scale; a.act = d->act;
   a.batch = d->batch > 0 ? d->batch : 1; a.sA = d->sA; a.sB = d->sB; a.sBias = d->sBias; a.sY = d->sY; a.sYs = d->sYs; a.sR = d->sR;
+  a.planes = d->planes == 1 ? 1 : 2;
   return gemm_ss(a, (hipStream_t)stream);
 }
 
@@ -653,6 +663,7 @@ int lbm_hip_conv2d_nhwc_ss(const void* X, int64_t x_plane, const void* W_hi, con
   c.zeros = zeros; c.scratch = scratch; c.scratch_bytes = scratch_bytes;
   c.B = B; c.H = H; c.Wd = Wd; c.Cin = Cin; c.Cout = Cout; c.kh = kh; c.kw = kw; c.stride = stride; c.pad = pad; c.relu = relu;
   c.ldw = ldw > 0 ? ldw : kh * kw * Cin;
+  c.planes = W_lo == nullptr ? 1 : 2;
   return conv2d_nhwc_ss(c, (hipStream_t)stream);
 }
 
@@ -697,8 +708,9 @@ int lbm_hip_track_step(const lbm_hip_step_desc* d, lbm_stream_t stream) {
     LBM_REQUIRE(d->query && d->stream_mem && d->coll_mem && d->vis_mask && d->mem_mask, "step: null state pointer");
     LBM_REQUIRE(d->vis && d->rho && d->offset, "step: vis/rho/offset outputs are required");
   }
-  st.split = d->precision == 1;
-  if (st.split) LBM_REQUIRE(d->weights_lo != nullptr, "step: precision 1 needs the lo planes of the weight matrices (weights_lo)");
+  st.split = d->precision >= 1;
+  st.planes = d->precision == 2 ? 1 : 2;
+  if (d->precision == 1) LBM_REQUIRE(d->weights_lo != nullptr, "step: precision 1 needs the lo planes of the weight matrices (weights_lo)");
   st.d = d;
   st.s = (hipStream_t)stream;
   st.ws = (char*)d->workspace;

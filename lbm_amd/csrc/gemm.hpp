@@ -76,6 +76,7 @@ struct GemmSSArgs {
   float* cand_v = nullptr;
   int* cand_i = nullptr;
   int topk_k = 0;
+  int planes = 2;               // 2: hi and lo planes (fp32-grade); 1: hi planes only (plain f16 operands, reduced precision)
 };
 int gemm_ss(const GemmSSArgs& a, hipStream_t stream);
 bool gemm_ss_topk_ok(int M, int N, int K, int batch, int k);   // would gemm_ss take the fused top-k path for this shape?
@@ -95,6 +96,7 @@ struct ConvSSArgs {
   void* scratch = nullptr;        // optional fp32 scratch for K-split slabs
   unsigned long long scratch_bytes = 0;
   int B = 0, H = 0, Wd = 0, Cin = 0, Cout = 0, kh = 0, kw = 0, stride = 1, pad = 0, relu = 0, ldw = 0;
+  int planes = 2;                 // as GemmSSArgs::planes
 };
 int conv2d_nhwc_ss(const ConvSSArgs& c, hipStream_t stream);
 int maxpool3x3s2_nhwc(const float* x, float* y, int B, int H, int W, int C, hipStream_t stream, void* ys = nullptr,

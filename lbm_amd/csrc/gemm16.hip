@@ -489,14 +489,16 @@ __device__ __forceinline__ void pf_steps(F& f) {
 // FULL: K / 32 == STAGES exactly; the DMA of the whole K extent is issued up front (STAGES x stage bytes of LDS, one
 // workgroup per CU).  This is the small-problem variant: with ~1 workgroup per CU nothing else hides the DMA
 // latency, so it is paid once per workgroup instead of once per chunk.
-template <int BM, int BN, int WM, int WN, int STAGES, bool CONV, bool FULL = false, int TOPK = 0>
+// NPL: operand planes staged and multiplied -- 2 = hi and lo (fp32-grade, three MFMAs per block), 1 = hi only (plain f16
+// operands, one MFMA per block, half the staging bytes: the reduced-precision mode, step precision 2).
+template <int BM, int BN, int WM, int WN, int STAGES, bool CONV, bool FULL = false, int TOPK = 0, int NPL = 2>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_ss_kernel(GemmSSDev a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // LDS-DMA builtins and s_waitcnt asm exist on the device side only
   constexpr int NW = WM * WN;
   constexpr int TM = BM / WM / 32;
   constexpr int TN = BN / WN / 32;
   constexpr int PLANE_A = BM * 64, PLANE_B = BN * 64;          // bytes of one plane of one stage
-  constexpr int STAGE = 2 * (PLANE_A + PLANE_B);
+  constexpr int STAGE = NPL * (PLANE_A + PLANE_B);             // [A hi][A lo][B hi][B lo] (NPL = 1: [A hi][B hi])
   constexpr int PIECES = STAGE / 1024;                         // 1-KiB DMA pieces per stage
   static_assert(PIECES % NW == 0, "DMA pieces must divide evenly over the waves");
   constexpr int PPW = PIECES / NW;                             // pieces (= DMA instructions) per wave and stage
@@ -521,8 +523,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_ss_kernel(GemmSSDev a) {
     c_iy0[i] = c_ix0[i] = 0;
     const int p = wave * PPW + i;                              // piece index inside the stage, in LDS order
     const int pb = p * 1024;
-    const bool isB = pb >= 2 * PLANE_A;
-    const int off = isB ? pb - 2 * PLANE_A : pb;
+    const bool isB = pb >= NPL * PLANE_A;
+    const int off = isB ? pb - NPL * PLANE_A : pb;
     const int plane_bytes = isB ? PLANE_B : PLANE_A;
     const int lo = off >= plane_bytes ? 1 : 0;
     const int row = (off - lo * plane_bytes) / 64 + (lane >> 2);
@@ -560,7 +562,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_ss_kernel(GemmSSDev a) {
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
       unsigned char* dst = lds + stage * STAGE + (wave * PPW + i) * 1024;
-      const bool isB = (wave * PPW + i) * 1024 >= 2 * PLANE_A;
+      const bool isB = (wave * PPW + i) * 1024 >= NPL * PLANE_A;
       const _Float16* g;
       if (CONV && !isB) {
         const bool ok = (unsigned)(c_iy0[i] + ky) < (unsigned)a.cH && (unsigned)(c_ix0[i] + kx) < (unsigned)a.cW;
@@ -608,8 +610,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_ss_kernel(GemmSSDev a) {
   // here: a scalar branch between the reads and the MFMAs stops that overlap (seen in the ISA of the first version).
   auto compute = [&](int stage) {
     const unsigned char* Ah = lds + stage * STAGE;
-    const unsigned char* Al = Ah + PLANE_A;
-    const unsigned char* Bh = Al + PLANE_A;
+    const unsigned char* Al = Ah + PLANE_A;                    // (NPL = 1: not staged, never read)
+    const unsigned char* Bh = Ah + NPL * PLANE_A;
     const unsigned char* Bl = Bh + PLANE_B;
     half8 fah[2][TM], fal[2][TM], fbh[2][TN], fbl[2][TN];
 #pragma unroll
@@ -617,12 +619,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_ss_kernel(GemmSSDev a) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         fah[s][i] = *reinterpret_cast<const half8*>(Ah + offA[i][s]);
-        fal[s][i] = *reinterpret_cast<const half8*>(Al + offA[i][s]);
+        if constexpr (NPL == 2) fal[s][i] = *reinterpret_cast<const half8*>(Al + offA[i][s]);
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         fbh[s][j] = *reinterpret_cast<const half8*>(Bh + offB[j][s]);
-        fbl[s][j] = *reinterpret_cast<const half8*>(Bl + offB[j][s]);
+        if constexpr (NPL == 2) fbl[s][j] = *reinterpret_cast<const half8*>(Bl + offB[j][s]);
       }
     }
 #pragma unroll
@@ -632,8 +634,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_ss_kernel(GemmSSDev a) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[s][i], fbh[s][j], acc[i][j], 0, 0, 0);
-          acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[s][i], fbl[s][j], acx[i][j], 0, 0, 0);
-          acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[s][i], fbh[s][j], acx[i][j], 0, 0, 0);
+          if constexpr (NPL == 2) {
+            acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[s][i], fbl[s][j], acx[i][j], 0, 0, 0);
+            acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[s][i], fbh[s][j], acx[i][j], 0, 0, 0);
+          }
         }
   };
   if constexpr (FULL) {
@@ -681,7 +685,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_ss_kernel(GemmSSDev a) {
         const int rl = (wm * TM + i) * 32 + 4 * h;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          float v = acc[i][j][e] + acx[i][j][e] * (1.0f / 2048.0f) + bv;
+          float v = (NPL == 2 ? acc[i][j][e] + acx[i][j][e] * (1.0f / 2048.0f) : acc[i][j][e]) + bv;
           if (a.act == ACT_GELU) v = gelu_erf(v);
           T[(rl + (e & 3) + 8 * (e >> 2)) * TP + cl] = v;
         }
@@ -789,7 +793,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_ss_kernel(GemmSSDev a) {
       for (int e = 0; e < 16; ++e) {
         const int row = rbase + (e & 3) + 8 * (e >> 2);
         if (row < a.M) {
-          float v = acc[i][j][e] + acx[i][j][e] * (1.0f / 2048.0f) + bv;
+          float v = (NPL == 2 ? acc[i][j][e] + acx[i][j][e] * (1.0f / 2048.0f) : acc[i][j][e]) + bv;
           if (a.act == ACT_GELU) v = gelu_erf(v);
           if (res) {
             int rr = row;
@@ -812,10 +816,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_ss_kernel(GemmSSDev a) {
 #endif
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, bool CONV = false, bool FULL = false, int TOPK = 0>
+template <int BM, int BN, int WM, int WN, int STAGES, bool CONV = false, bool FULL = false, int TOPK = 0, int NPL = 2>
 static int launch_ss(const GemmSSDev& d, int batch, hipStream_t stream) {
   dim3 grid((d.N + BN - 1) / BN, (d.M + BM - 1) / BM, batch);
-  static const std::string name = std::string(CONV ? "conv_ss" : TOPK ? "gemm_ss_topk" + std::to_string(TOPK) : "gemm_ss") + (FULL ? "_full<" : "<") + std::to_string(BM) + "," + std::to_string(BN) + "," + std::to_string(WM) +
+  static const std::string name = std::string(CONV ? "conv_s" : TOPK ? "gemm_ss_topk" + std::to_string(TOPK) : "gemm_s") + (TOPK ? "" : NPL == 2 ? "s" : "h") + (FULL ? "_full<" : "<") + std::to_string(BM) + "," + std::to_string(BN) + "," + std::to_string(WM) +
                                   "," + std::to_string(WN) + "," + std::to_string(STAGES) + ">";
   const double mnk = (double)d.M * d.N * d.K * batch;
   static const bool by_shape = getenv("LBM_PROF_SHAPES") != nullptr;      // profiling aid: one entry per problem shape
@@ -828,20 +832,20 @@ static int launch_ss(const GemmSSDev& d, int batch, hipStream_t stream) {
   ProfScope prof(by_shape ? interned.insert(shaped).first->c_str() : name.c_str(), stream, 2.0 * mnk,
                  4.0 * ((double)d.M * d.K * batch + (double)d.N * d.K * (d.sB || batch == 1 ? batch : 1) +
                         (double)d.M * d.N * batch * ((d.Y ? 1 : 0) + (d.Ys ? 1 : 0) + (d.res ? 1 : 0))));
-  hipLaunchKernelGGL((gemm_ss_kernel<BM, BN, WM, WN, STAGES, CONV, FULL, TOPK>), grid, dim3(WM * WN * 64), 0, stream, dv);
+  hipLaunchKernelGGL((gemm_ss_kernel<BM, BN, WM, WN, STAGES, CONV, FULL, TOPK, NPL>), grid, dim3(WM * WN * 64), 0, stream, dv);
   return check_launch(CONV ? "conv_ss" : "gemm_ss");
 }
 
 // 64x64 tiles with the whole K extent prefetched (K / 32 chunks resident): the variant for grids of <= ~2 workgroups per CU
-template <bool CONV>
+template <bool CONV, int NPL = 2>
 static int launch_full(const GemmSSDev& d, int batch, hipStream_t stream, bool* handled) {
   *handled = true;
   switch (d.K / 32) {
-    case 2: return launch_ss<64, 64, 2, 2, 2, CONV, true>(d, batch, stream);
-    case 4: return launch_ss<64, 64, 2, 2, 4, CONV, true>(d, batch, stream);
-    case 6: return launch_ss<64, 64, 2, 2, 6, CONV, true>(d, batch, stream);
-    case 8: return launch_ss<64, 64, 2, 2, 8, CONV, true>(d, batch, stream);
-    case 9: return launch_ss<64, 64, 2, 2, 9, CONV, true>(d, batch, stream);
+    case 2: return launch_ss<64, 64, 2, 2, 2, CONV, true, 0, NPL>(d, batch, stream);
+    case 4: return launch_ss<64, 64, 2, 2, 4, CONV, true, 0, NPL>(d, batch, stream);
+    case 6: return launch_ss<64, 64, 2, 2, 6, CONV, true, 0, NPL>(d, batch, stream);
+    case 8: return launch_ss<64, 64, 2, 2, 8, CONV, true, 0, NPL>(d, batch, stream);
+    case 9: return launch_ss<64, 64, 2, 2, 9, CONV, true, 0, NPL>(d, batch, stream);
     default: break;
   }
   *handled = false;
@@ -874,8 +878,31 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
   }
 }
 
+template <int NPL>
+static int conv_launch(const ConvSSArgs& c, GemmSSDev& d, int nsplit, int nk, long long big, long long mid, long long M, int K,
+                       hipStream_t stream) {
+  if (nsplit == 1) {
+    d.bias = c.bias; d.res = c.res; d.act = c.relu ? ACT_RELU_POST : ACT_NONE;
+    d.Y = c.Y; d.Ys = (_Float16*)c.Ys; d.ys_plane = c.ys_plane; d.kt0_per_z = 0;
+    if (mid <= 640 && full_ok(nk)) {
+      bool handled;
+      const int rc = launch_full<true, NPL>(d, 1, stream, &handled);
+      if (handled) return rc;
+    }
+    if (big >= 128 && c.Cout > 64) return launch_ss<128, 128, 2, 4, 2, true, false, 0, NPL>(d, 1, stream);
+    return mid <= 320 ? launch_ss<64, 64, 2, 2, 4, true, false, 0, NPL>(d, 1, stream)
+                      : launch_ss<64, 64, 2, 2, 2, true, false, 0, NPL>(d, 1, stream);
+  }
+  d.Y = (float*)c.scratch; d.sY = M * c.Cout; d.K = K / nsplit; d.kt0_per_z = nk / nsplit; d.act = ACT_NONE;
+  bool handled;
+  if (launch_full<true, NPL>(d, nsplit, stream, &handled)) return -1;
+  if (!handled && launch_ss<64, 64, 2, 2, 2, true, false, 0, NPL>(d, nsplit, stream)) return -1;
+  return 0;
+}
+
 int conv2d_nhwc_ss(const ConvSSArgs& c, hipStream_t stream) {
-  LBM_REQUIRE(c.X && c.Wh && c.Wl && (c.Y || c.Ys) && c.zeros, "conv2d_ss: null argument");
+  LBM_REQUIRE(c.X && c.Wh && (c.Wl || c.planes == 1) && (c.Y || c.Ys) && c.zeros, "conv2d_ss: null argument");
+  LBM_REQUIRE(c.planes == 1 || c.planes == 2, "conv2d_ss: planes must be 1 or 2");
   LBM_REQUIRE(c.B >= 1 && c.H >= 1 && c.Wd >= 1 && c.Cout >= 1, "conv2d_ss: bad shape");
   int lg = 0;
   while ((1 << lg) < c.Cin) ++lg;
@@ -885,14 +912,14 @@ int conv2d_nhwc_ss(const ConvSSArgs& c, hipStream_t stream) {
   LBM_REQUIRE(Ho >= 1 && Wo >= 1, "conv2d_ss: empty output");
   const int K = c.kh * c.kw * c.Cin;
   LBM_REQUIRE(c.ldw >= K && c.ldw % 8 == 0, "conv2d_ss: packed weight rows need %d columns, have %d", K, c.ldw);
-  LBM_REQUIRE(((uintptr_t)c.X & 15) == 0 && ((uintptr_t)c.Wh & 15) == 0 && ((uintptr_t)c.Wl & 15) == 0 && ((uintptr_t)c.zeros & 15) == 0 &&
+  LBM_REQUIRE(((uintptr_t)c.X & 15) == 0 && ((uintptr_t)c.Wh & 15) == 0 && (c.Wl == nullptr || ((uintptr_t)c.Wl & 15) == 0) && ((uintptr_t)c.zeros & 15) == 0 &&
                   c.x_plane % 8 == 0,
               "conv2d_ss: operands must be 16-byte aligned");
   const long long M = (long long)c.B * Ho * Wo;
   LBM_REQUIRE(M < 0x7fffffffLL, "conv2d_ss: too many output pixels");
   GemmSSDev d{};
   d.A = (const _Float16*)c.X; d.a_plane = c.x_plane; d.B = (const _Float16*)c.Wh;
-  d.b_plane = ((const char*)c.Wl - (const char*)c.Wh) / 2; d.ldb = c.ldw;
+  d.b_plane = c.Wl ? ((const char*)c.Wl - (const char*)c.Wh) / 2 : 0; d.ldb = c.ldw;
   d.M = (int)M; d.N = c.Cout; d.K = K; d.ldy = c.Cout; d.ldys = c.Cout; d.ldres = c.Cout;
   d.res_div = 1; d.res_mod = 0x7fffffff; d.res_scale = 1.f;
   d.cH = c.H; d.cW = c.Wd; d.cin_log2 = lg; d.ckw = c.kw; d.cstride = c.stride; d.cpad = c.pad; d.cHo = Ho; d.cWo = Wo;
@@ -929,23 +956,12 @@ int conv2d_nhwc_ss(const ConvSSArgs& c, hipStream_t stream) {
     }
     if (!full_ok(nk / nsplit)) nsplit = 1;
   }
-  if (nsplit == 1) {
-    d.bias = c.bias; d.res = c.res; d.act = c.relu ? ACT_RELU_POST : ACT_NONE;
-    d.Y = c.Y; d.Ys = (_Float16*)c.Ys; d.ys_plane = c.ys_plane; d.kt0_per_z = 0;
-    if (mid <= 640 && full_ok(nk)) {
-      bool handled;
-      const int rc = launch_full<true>(d, 1, stream, &handled);
-      if (handled) return rc;
-    }
-    if (big >= 128 && c.Cout > 64) return launch_ss<128, 128, 2, 4, 2, true>(d, 1, stream);
-    return mid <= 320 ? launch_ss<64, 64, 2, 2, 4, true>(d, 1, stream) : launch_ss<64, 64, 2, 2, 2, true>(d, 1, stream);
+  if (c.planes == 1) {
+    if (conv_launch<1>(c, d, nsplit, nk, big, mid, M, K, stream)) return -1;
+  } else if (conv_launch<2>(c, d, nsplit, nk, big, mid, M, K, stream)) {
+    return -1;
   }
-  d.Y = (float*)c.scratch; d.sY = M * c.Cout; d.K = K / nsplit; d.kt0_per_z = nk / nsplit; d.act = ACT_NONE;
-  {
-    bool handled;
-    if (launch_full<true>(d, nsplit, stream, &handled)) return -1;
-    if (!handled && launch_ss<64, 64, 2, 2, 2, true>(d, nsplit, stream)) return -1;
-  }
+  if (nsplit == 1) return 0;
   const long long total4 = M * c.Cout / 4;
   long long blocks = (total4 + 255) / 256;
   if (blocks > 65535) blocks = 65535;
@@ -991,6 +1007,16 @@ int gemm_ss(const GemmSSArgs& a, hipStream_t stream) {
   const long long big = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.batch;
   int t = g_force_tile16;
   const long long mid = (long long)((a.M + 63) / 64) * ((a.N + 63) / 64) * a.batch;
+  LBM_REQUIRE(a.planes == 1 || a.planes == 2, "gemm_ss: planes must be 1 or 2");
+  if (a.planes == 1) {           // hi planes only: the same three tilings, one MFMA per block
+    if (mid <= 640 && full_ok(a.K / 32)) {
+      bool handled;
+      const int rc = launch_full<false, 1>(d, a.batch, stream, &handled);
+      if (handled) return rc;
+    }
+    return (big >= 128 && a.N > 64) ? launch_ss<128, 128, 2, 4, 2, false, false, 0, 1>(d, a.batch, stream)
+                                    : launch_ss<64, 64, 2, 2, 2, false, false, 0, 1>(d, a.batch, stream);
+  }
   if ((t == 0 && mid <= 640 && full_ok(a.K / 32)) || t == 20) {
     bool handled;
     const int rc = launch_full<false>(d, a.batch, stream, &handled);

@@ -52,6 +52,11 @@ def _pack_conv(w: torch.Tensor, cin_pad: int = 0) -> torch.Tensor:
     return flat.contiguous()
 
 
+# "split": fp32 operands as f16 hi/lo planes, three MFMAs per block (fp32-grade, the default); "f32": exact fp32 MFMA;
+# "f16": hi planes only, one MFMA per block (the reduced-precision mode: 1e-2 on logits)
+PRECISIONS = ("split", "f32", "f16")
+
+
 class _Conv:
     def __init__(self, w, b, kh, stride, pad, dev):
         self.w = w.to(dev, torch.float32).contiguous()
@@ -67,18 +72,20 @@ class _Conv:
         """fp32 NHWC in (split in the loader) -> fp32 NHWC out on the f16 matrix cores (the 4-channel RGB stem)."""
         return hip.conv2d_nhwc(x, self.ws, self.b, self.kh, self.kh, self.stride, self.pad, relu, res)
 
-    def split(self, xs, relu, res=None, want_f32=True, want_split=True, scratch=None):
+    def split(self, xs, relu, res=None, want_f32=True, want_split=True, scratch=None, planes=2):
         """split NHWC in -> (fp32, split) out; im2col rows gathered by LDS-DMA."""
-        return hip.conv2d_nhwc_ss(xs, self.ws, self.b, self.kh, self.stride, self.pad, relu, res, want_f32, want_split, scratch)
+        return hip.conv2d_nhwc_ss(xs, self.ws, self.b, self.kh, self.stride, self.pad, relu, res, want_f32, want_split, scratch,
+                                  planes)
 
 
 class EncoderWeights:
     def __init__(self, bb, precision: Optional[str] = None):
         import os
         precision = precision or os.environ.get("LBM_AMD_PRECISION", "split")
-        if precision not in ("split", "f32"):
-            raise ValueError("precision must be 'split' or 'f32'")
+        if precision not in PRECISIONS:
+            raise ValueError(f"precision must be one of {PRECISIONS}")
         self.precision = precision
+        self.planes = 1 if precision == "f16" else 2
         dev = bb.frame_pos_embedding.device
         if dev.type != "cuda":
             raise hip.HipError("the encoder runs on the GPU only: move the model with .cuda() first")
@@ -128,7 +135,7 @@ class EncoderWeights:
         return self._body(x, add_pos, None)
 
     def _body(self, x: torch.Tensor, add_pos: bool, out: Optional[torch.Tensor]) -> torch.Tensor:
-        if self.precision == "split":
+        if self.precision in ("split", "f16"):
             return self._body_split(x, add_pos, out)
         self.tokens_split = None
         B = x.shape[0]
@@ -163,14 +170,14 @@ class EncoderWeights:
         y, ys = hip.maxpool3x3s2_nhwc_s(y)
         feats = []
         for i, (c1, c2, down) in enumerate(self.blocks):
-            idn = y if down is None else down.split(ys, False, want_split=False, scratch=self._scratch)[0]
-            _, ts = c1.split(ys, True, want_f32=False, scratch=self._scratch)
-            y, ys = c2.split(ts, True, idn, scratch=self._scratch)
+            idn = y if down is None else down.split(ys, False, want_split=False, scratch=self._scratch, planes=self.planes)[0]
+            _, ts = c1.split(ys, True, want_f32=False, scratch=self._scratch, planes=self.planes)
+            y, ys = c2.split(ts, True, idn, scratch=self._scratch, planes=self.planes)
             if i % 2 == 1:
                 feats.append(ys)
         ps = []
         for f, pw, (_, pb) in zip(feats, self.proj_s, self.proj):
-            ps.append(hip.linear_ss(f.reshape(-1, f.shape[-1]), pw, pb)[0])
+            ps.append(hip.linear_ss(f.reshape(-1, f.shape[-1]), pw, pb, planes=self.planes)[0])
         cat = hip.upcat_s(ps[0], ps[1], ps[2], B, self.h, self.w)
         if out is None:
             out = torch.empty(B, self.L, 256, device=self.dev, dtype=torch.float32)
@@ -178,7 +185,7 @@ class EncoderWeights:
         hip.linear_ss_raw(A=cat.hi, a_plane=cat.plane, B=self.fusion_ws.hi, b_plane=self.fusion_ws.planes[0].numel(),
                           bias=self.fusion_b.data_ptr(), Y=out.data_ptr(), res=self.pos.data_ptr() if add_pos else None,
                           M=P0, N=256, K=192, lda=192, ldb=192, ldy=256, ldres=256, res_div=1, res_mod=0, res_scale=1.0, act=1,
-                          batch=B, sA=P0 * 192, sB=0, sBias=0, sY=self.L * 256, sR=0)
+                          batch=B, sA=P0 * 192, sB=0, sBias=0, sY=self.L * 256, sR=0, planes=self.planes)
         target, self._split_target = self._split_target, None
         if target is None:      # the encoder's own twin; a caller-owned one (pipelined slots) is never reused for another frame
             if self._own_split is None or self._own_split.shape != (B, self.L, 256):
@@ -331,8 +338,8 @@ class TrackEngine:
         the environment variable LBM_AMD_PRECISION overrides the default."""
         import os
         precision = precision or os.environ.get("LBM_AMD_PRECISION", "split")
-        if precision not in ("split", "f32"):
-            raise ValueError("precision must be 'split' or 'f32'")
+        if precision not in PRECISIONS:
+            raise ValueError(f"precision must be one of {PRECISIONS}")
         self.precision = precision
         # optional point-parallel sub-streams (B == 1): the per-point chain of up to 1 + n_aux row ranges is enqueued on
         # concurrent HIP streams.  Off by default: measured on MI355X it does not shorten the step (host-bound eagerly,
@@ -358,8 +365,8 @@ class TrackEngine:
             d.corr_mix[i] = v
         for i, v in enumerate(self.w.corr_bias):
             d.corr_bias[i] = v
-        if self.precision == "split":
-            d.precision = 1
+        if self.precision in ("split", "f16"):
+            d.precision = 1 if self.precision == "split" else 2
             d.weights = C.cast(self.w.table_hi, C.POINTER(C.c_void_p))
             d.weights_lo = C.cast(self.w.table_lo, C.POINTER(C.c_void_p))
         else:
@@ -402,7 +409,7 @@ class TrackEngine:
         d.ring_head, d.update_state = ring_head, 1 if update_state else 0
         ih, iw = img_hw if img_hw is not None else cfg.input_size
         d.img_h, d.img_w = float(ih), float(iw)
-        if tokens_split is not None and d.precision == 1:
+        if tokens_split is not None and d.precision >= 1:
             if tokens_split.shape != tuple(tokens.shape):
                 raise hip.HipError("tokens_split does not match tokens")
             d.tokens_split = tokens_split.hi

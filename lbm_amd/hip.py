@@ -51,7 +51,7 @@ class LinearSSDesc(C.Structure):
                 ("ldy", C.c_int32), ("ldys", C.c_int32), ("ldres", C.c_int32), ("res_div", C.c_int32), ("res_mod", C.c_int32),
                 ("res_scale", C.c_float), ("act", C.c_int32), ("batch", C.c_int32),
                 ("sA", C.c_int64), ("sB", C.c_int64), ("sBias", C.c_int64), ("sY", C.c_int64), ("sYs", C.c_int64),
-                ("sR", C.c_int64)]
+                ("sR", C.c_int64), ("planes", C.c_int32)]
 
 
 class MsdaDesc(C.Structure):
@@ -258,7 +258,7 @@ def zero_page(device) -> int:
 
 def conv2d_nhwc_ss(x: "SplitTensor", w: "SplitWeight", bias: torch.Tensor, kh: int, stride: int, pad: int, relu: bool,
                    res: Optional[torch.Tensor] = None, want_f32: bool = True, want_split: bool = True,
-                   scratch: Optional[torch.Tensor] = None):
+                   scratch: Optional[torch.Tensor] = None, planes: int = 2):
     """Split-precision NHWC convolution: x (B,H,W,Cin) split, packed weights split -> (y fp32 | None, ys SplitTensor | None)."""
     _require_gpu()
     B, H, W, Cin = x.shape
@@ -268,7 +268,7 @@ def conv2d_nhwc_ss(x: "SplitTensor", w: "SplitWeight", bias: torch.Tensor, kh: i
     dev = x.planes.device
     y = torch.empty(B, Ho, Wo, Cout, device=dev, dtype=torch.float32) if want_f32 else None
     ys = SplitTensor((B, Ho, Wo, Cout), dev) if want_split else None
-    _check(load().lbm_hip_conv2d_nhwc_ss(x.hi, x.plane, w.hi, w.lo, _p(bias), _p(res), _p(y), ys.hi if ys else None,
+    _check(load().lbm_hip_conv2d_nhwc_ss(x.hi, x.plane, w.hi, w.lo if planes == 2 else None, _p(bias), _p(res), _p(y), ys.hi if ys else None,
                                          ys.plane if ys else 0, zero_page(dev), _p(scratch, None) if scratch is not None else None,
                                          scratch.numel() * scratch.element_size() if scratch is not None else 0,
                                          B, H, W, Cin, Cout, kh, kh, stride, pad, 1 if relu else 0, w.shape[1], _stream()),
@@ -308,8 +308,9 @@ def linear_ss_raw(**kw) -> None:
 
 
 def linear_ss(a: "SplitWeight", b: "SplitWeight", bias=None, act: int = 0, res=None, res_scale: float = 1.0,
-              want_f32: bool = True, want_split: bool = False):
-    """y = act(a @ b.T + bias) + res_scale * res with both operands pre-split; returns fp32 and/or SplitWeight-like."""
+              want_f32: bool = True, want_split: bool = False, planes: int = 2):
+    """y = act(a @ b.T + bias) + res_scale * res with both operands pre-split; returns fp32 and/or SplitWeight-like.
+    planes=1 multiplies the hi planes only (plain f16 operands: the reduced-precision mode)."""
     _require_gpu()
     M, K = a.shape
     N = b.shape[0]
@@ -321,6 +322,7 @@ def linear_ss(a: "SplitWeight", b: "SplitWeight", bias=None, act: int = 0, res=N
     d.Y, d.Ys, d.ys_plane = _p(y), (ys.data_ptr() if ys is not None else None), M * N
     d.M, d.N, d.K, d.lda, d.ldb, d.ldy, d.ldys, d.ldres = M, N, K, K, K, N, N, N
     d.res_div, d.res_mod, d.res_scale, d.act, d.batch = 1, 0, res_scale, act, 1
+    d.planes = planes
     _check(load().lbm_hip_linear_ss(C.byref(d), _stream()), "lbm_hip_linear_ss")
     return y, ys
 

@@ -45,7 +45,8 @@ class LBM(nn.Module):
                                           dropout=self.dropout)
 
     def set_precision(self, precision) -> None:
-        """"split" (default): contractions on the f16 matrix cores with split operands, fp32-grade; "f32": exact fp32 MFMA."""
+        """"split" (default): contractions on the f16 matrix cores with split operands, fp32-grade; "f32": exact fp32 MFMA;
+        "f16": reduced precision (plain f16 operands, fp32 accumulate; 1e-2 on logits), ~20 % faster."""
         self.backbone.set_precision(precision)
         self.transformer.set_precision(precision)
 

@@ -210,7 +210,7 @@ class LBM_online(LBM):
         frames.record_stream(enc)
         H, W = frames.shape[-2], frames.shape[-1]
         with torch.cuda.stream(enc):
-            if p["tok_s"][slot] is None and self.backbone.packed().precision == "split":
+            if p["tok_s"][slot] is None and self.backbone.packed().precision in ("split", "f16"):
                 p["tok_s"][slot] = hip.SplitTensor(tuple(p["tok"][slot].shape), frames.device)
             tok = self.backbone.encode_tokens(frames, p["tok"][slot], split_out=p["tok_s"][slot])
             self.transformer.get_engine().step(tok, self.query, self._stream, self._coll, self._vis, self._mem,

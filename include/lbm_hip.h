@@ -284,6 +284,17 @@ typedef struct {
   int32_t phase, row_lo, row_count, sub_index;
 } lbm_hip_step_desc;
 
+/* Add / remove tracked points without a host round trip.  Replaces the state edit of LBM_online.update
+ * (lbm_online.py:84-110): the old rows with remove_mask == 0 move, in order, to the front of the new state
+ * (query, both memories in their physical ring order -- the caller's ring head is unchanged --, both masks); rows with
+ * update_mask != 0 take new_query[row] and an empty memory (every slot ignored); all other rows are zero / ignored.
+ * The kept-row count is computed and consumed on the device (the reference's .item() / nonzero syncs are gone).
+ * scratch: N_old + 1 int32.  The new state must not alias the old one.                                          */
+int lbm_hip_update_points(const uint8_t* remove_mask, int32_t N_old, const uint8_t* update_mask, int32_t N_new, int32_t M,
+                          const float* old_query, const float* old_stream, const float* old_coll, const uint8_t* old_vis,
+                          const uint8_t* old_mem, const float* new_query, float* query, float* stream_mem, float* coll_mem,
+                          uint8_t* vis_mask, uint8_t* mem_mask, int32_t* scratch, lbm_stream_t stream);
+
 /* bytes of workspace lbm_hip_track_step needs for this geometry (only B, N, M, n_layers, topk, net_* are read) */
 uint64_t lbm_hip_step_workspace_bytes(const lbm_hip_step_desc* d);
 int lbm_hip_track_step(const lbm_hip_step_desc* d, lbm_stream_t stream);

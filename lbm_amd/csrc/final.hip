@@ -87,4 +87,73 @@ int state_final(const StateFinalArgs& a, hipStream_t stream) {
   return check_launch("state_final");
 }
 
+// ---- dynamic point set ---------------------------------------------------------------------------------------------
+// one workgroup: src[rank] = i for every kept old row i (rank = number of kept rows before it), src[N_old] = kept count
+__global__ __launch_bounds__(1024) void update_scan_kernel(const uint8_t* __restrict__ remove_mask, int N_old, int* __restrict__ src) {
+  __shared__ int wsum[16];
+  __shared__ int base;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) base = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < N_old; i0 += 1024) {
+    const int i = i0 + tid;
+    const int keep = (i < N_old && remove_mask[i] == 0) ? 1 : 0;
+    const unsigned long long b = __ballot(keep);
+    const int before = __popcll(b & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wave] = __popcll(b);
+    __syncthreads();
+    int off = base;
+    for (int w = 0; w < wave; ++w) off += wsum[w];
+    if (keep) src[off + before] = i;
+    __syncthreads();
+    if (tid == 0) {
+      int t = 0;
+      for (int w = 0; w < 16; ++w) t += wsum[w];
+      base += t;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) src[N_old] = base;
+}
+
+// one wave per row of the new state
+__global__ __launch_bounds__(256) void update_gather_kernel(UpdatePointsArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int d = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (d >= a.N_new) return;
+  const int n_prev = a.scratch[a.N_old];
+  const bool fresh = a.update_mask[d] != 0;
+  const int s = (!fresh && d < n_prev) ? a.scratch[d] : -1;          // old row that moves here, if any
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 q = zero;
+  if (fresh) q = ld4(a.new_query + (long long)d * LBM_C + lane * 4);
+  else if (s >= 0) q = ld4(a.old_query + (long long)s * LBM_C + lane * 4);
+  st4(a.query + (long long)d * LBM_C + lane * 4, q);
+  for (int j = 0; j < a.M; ++j) {
+    const long long o = ((long long)d * a.M + j) * LBM_C + lane * 4;
+    const long long so = ((long long)s * a.M + j) * LBM_C + lane * 4;
+    st4(a.stream + o, s >= 0 ? ld4(a.old_stream + so) : zero);
+    st4(a.coll + o, s >= 0 ? ld4(a.old_coll + so) : zero);
+  }
+  for (int j = lane; j < a.M; j += 64) {
+    a.vis[(long long)d * a.M + j] = s >= 0 ? a.old_vis[(long long)s * a.M + j] : 1;   // fresh / empty rows: every slot ignored
+    a.mem[(long long)d * a.M + j] = s >= 0 ? a.old_mem[(long long)s * a.M + j] : 1;
+  }
+}
+
+int update_points(const UpdatePointsArgs& a, hipStream_t stream) {
+  LBM_REQUIRE(a.N_old >= 0 && a.N_new >= 0 && a.M >= 1, "update_points: bad sizes");
+  if (a.N_new == 0) return 0;
+  LBM_REQUIRE(a.update_mask && a.new_query && a.query && a.stream && a.coll && a.vis && a.mem && a.scratch,
+              "update_points: null argument");
+  LBM_REQUIRE(a.N_old == 0 || (a.remove_mask && a.old_query && a.old_stream && a.old_coll && a.old_vis && a.old_mem),
+              "update_points: null old state");
+  LBM_REQUIRE(a.query != a.old_query && a.stream != a.old_stream && a.coll != a.old_coll, "update_points: the new state must not alias the old one");
+  ProfScope prof("update_points", stream, 0.0, 8.0 * LBM_C * (double)a.N_new * (2.0 * a.M + 1.0));
+  hipLaunchKernelGGL(update_scan_kernel, dim3(1), dim3(1024), 0, stream, a.remove_mask, a.N_old, a.scratch);
+  if (check_launch("update_scan")) return -1;
+  hipLaunchKernelGGL(update_gather_kernel, dim3((a.N_new + 3) / 4), dim3(256), 0, stream, a);
+  return check_launch("update_gather");
+}
+
 }  // namespace lbm

@@ -33,4 +33,26 @@ struct StateFinalArgs {
 
 int state_final(const StateFinalArgs& a, hipStream_t stream);
 
+// Add / remove tracked points on the device (lbm_online.py:48-112): rows of the old state that are kept move, in order,
+// to the front of the new state; rows flagged in update_mask take the freshly sampled query and an empty (all-ignored)
+// memory; any other row is zero.  No host round trip: the number of kept rows is computed and consumed on the device.
+struct UpdatePointsArgs {
+  const uint8_t* remove_mask = nullptr;   // [N_old] non-zero = drop the point
+  const uint8_t* update_mask = nullptr;   // [N_new] non-zero = (re)initialise from new_query
+  int N_old = 0, N_new = 0, M = 0;
+  const float* old_query = nullptr;       // [N_old, 256]
+  const float* old_stream = nullptr;      // [N_old, M, 256] (physical ring order; the ring head does not change)
+  const float* old_coll = nullptr;
+  const uint8_t* old_vis = nullptr;       // [N_old, M]
+  const uint8_t* old_mem = nullptr;
+  const float* new_query = nullptr;       // [N_new, 256] samples at the new query points (rows outside update_mask unused)
+  float* query = nullptr;                 // outputs, [N_new, ...]
+  float* stream = nullptr;
+  float* coll = nullptr;
+  uint8_t* vis = nullptr;
+  uint8_t* mem = nullptr;
+  int* scratch = nullptr;                 // N_old + 1 ints
+};
+int update_points(const UpdatePointsArgs& a, hipStream_t stream);
+
 }  // namespace lbm

@@ -27,6 +27,7 @@ EXPORTS = (
     "lbm_hip_track_step", "lbm_hip_step_workspace_offset", "lbm_hip_conv2d_nhwc", "lbm_hip_maxpool3x3s2_nhwc",
     "lbm_hip_profile_begin", "lbm_hip_profile_end", "lbm_hip_split_planes", "lbm_hip_debug_set", "lbm_hip_linear_ss",
     "lbm_hip_conv2d_nhwc_ss", "lbm_hip_maxpool3x3s2_nhwc_s", "lbm_hip_upcat_s", "lbm_hip_pyramid_s",
+    "lbm_hip_update_points",
 )
 
 
@@ -136,6 +137,7 @@ def load() -> C.CDLL:
     lib.lbm_hip_preprocess.argtypes = [C.c_void_p, C.c_int64, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p]
     lib.lbm_hip_upcat.argtypes = [C.c_void_p] * 4 + [C.c_int32] * 3 + [C.c_void_p]
     lib.lbm_hip_sample_queries.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p]
+    lib.lbm_hip_update_points.argtypes = ([C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 13)
     lib.lbm_hip_step_workspace_bytes.argtypes = [C.POINTER(StepDesc)]
     lib.lbm_hip_track_step.argtypes = [C.POINTER(StepDesc), C.c_void_p]
     lib.lbm_hip_conv2d_nhwc.argtypes = [C.c_void_p] * 6 + [C.c_int32] * 11 + [C.c_void_p]
@@ -274,6 +276,30 @@ def conv2d_nhwc_ss(x: "SplitTensor", w: "SplitWeight", bias: torch.Tensor, kh: i
                                          B, H, W, Cin, Cout, kh, kh, stride, pad, 1 if relu else 0, w.shape[1], _stream()),
            "lbm_hip_conv2d_nhwc_ss")
     return y, ys
+
+
+def update_points(remove_mask: torch.Tensor, update_mask: torch.Tensor, old, new_query: torch.Tensor, M: int):
+    """Device-side edit of the tracked point set (lbm_hip_update_points).  old = (query (1,N_old,C), stream, coll (1,N_old,M,C),
+    vis, mem (1,N_old,M) uint8) or None; returns the new (query, stream, coll, vis, mem) for N_new = len(update_mask) points."""
+    _require_gpu()
+    dev = new_query.device
+    N_new = int(update_mask.shape[0])
+    N_old = 0 if old is None else int(old[0].shape[1])
+    Cc = new_query.shape[-1]
+    query = torch.empty(1, N_new, Cc, device=dev)
+    stream = torch.empty(1, N_new, M, Cc, device=dev)
+    coll = torch.empty(1, N_new, M, Cc, device=dev)
+    vis = torch.empty(1, N_new, M, device=dev, dtype=torch.uint8)
+    mem = torch.empty(1, N_new, M, device=dev, dtype=torch.uint8)
+    scratch = torch.empty(N_old + 1, device=dev, dtype=torch.int32)
+    rm = remove_mask.to(torch.uint8).contiguous() if N_old else None
+    um = update_mask.to(torch.uint8).contiguous()
+    o = old if N_old else (None,) * 5
+    _check(load().lbm_hip_update_points(_p(rm, torch.uint8), N_old, _p(um, torch.uint8), N_new, M, _p(o[0]), _p(o[1]), _p(o[2]),
+                                        _p(o[3], torch.uint8), _p(o[4], torch.uint8), _p(new_query.contiguous()), _p(query),
+                                        _p(stream), _p(coll), _p(vis, torch.uint8), _p(mem, torch.uint8), scratch.data_ptr(),
+                                        _stream()), "lbm_hip_update_points")
+    return query, stream, coll, vis, mem
 
 
 def maxpool3x3s2_nhwc_s(x: torch.Tensor):

@@ -123,27 +123,22 @@ class LBM_online(LBM):
         if N > 0:
             if frame_feat.dim() == 4:       # (1,C,h,w) view -> token-major
                 frame_feat = frame_feat.permute(0, 2, 3, 1).reshape(1, self.h * self.w, self.embed_dim)
-            remove_mask = remove_mask[: self.N].bool()
-            update_mask = update_mask.bool()
-            keep = ~remove_mask
-            n_prev = int(keep.sum())
-            pts = self._to_net_px(query_points[update_mask].to(self.device)).unsqueeze(0).contiguous()
-            new_q = self.backbone.sample_points(frame_feat, pts)            # (1, n_update, C)
-            old = (self.query, self._stream, self._coll, self._vis, self._mem, self._head)
-            self._alloc_state(1, N)
-            query = torch.zeros(1, N, self.embed_dim, device=self.device)
-            if old[0] is not None and n_prev > 0:
-                M = self.memory_size
-                order = (torch.arange(M, device=self.device) + old[5]) % M   # back to logical order, head = 0
-                query[:, :n_prev] = old[0][:, keep]
-                self._stream[:, :n_prev] = old[1][:, keep].index_select(2, order)
-                self._coll[:, :n_prev] = old[2][:, keep].index_select(2, order)
-                self._vis[:, :n_prev] = old[3][:, keep].index_select(2, order)
-                self._mem[:, :n_prev] = old[4][:, keep].index_select(2, order)
-                query[:, update_mask] = new_q
+            dev = frame_feat.device
+            self.device = dev
+            # every point is sampled (N bilinear reads) and the device picks the rows it needs: no boolean indexing,
+            # no .item(), nothing the host has to wait for (the reference syncs three times here, lbm_online.py:57-83)
+            pts = self._to_net_px(query_points.to(dev)).unsqueeze(0).contiguous()
+            new_q = self.backbone.sample_points(frame_feat, pts)            # (1, N, C)
+            old = None
+            if self.query is not None and self.N > 0:
+                old = (self.query, self._stream, self._coll, self._vis, self._mem)
+                remove = remove_mask[: self.N].to(dev)
             else:
-                query = new_q
-            self.query = query.contiguous()
+                remove = None
+                self._head = 0
+            # the ring head is untouched: kept rows move in their physical slot order
+            self.query, self._stream, self._coll, self._vis, self._mem = hip.update_points(
+                remove, update_mask.to(dev), old, new_q, self.memory_size)
             self.query_points = query_points
         self.N = N
         self.B = 1

@@ -671,3 +671,49 @@ def test_reduced_precision_encoder_and_online_tracker(hip):
     close = ((runs["split"][0] - runs["f16"][0]).abs().max(-1).values < 1.0)
     assert close.float().mean().item() >= 0.95
     assert (runs["split"][1] == runs["f16"][1]).float().mean().item() >= 0.95
+
+
+@pytest.mark.parametrize("N_old,N_new", [(0, 5), (9, 9), (700, 900), (2500, 1800)])
+def test_update_points_kernel_against_the_reference_edit(hip, N_old, N_new):
+    """lbm_hip_update_points against the reference's own sequence of tensor edits (lbm_online.py:84-110): kept rows to
+    the front in order, update_mask rows overwritten with the new samples (also inside the kept range), the rest empty."""
+    r = np.random.default_rng(N_old + N_new)
+    M, Cc = 5, 256
+    t = lambda *s: torch.from_numpy(r.normal(size=s).astype(np.float32)).cuda()
+    old = None
+    remove = None
+    if N_old:
+        old = (t(1, N_old, Cc), t(1, N_old, M, Cc), t(1, N_old, M, Cc),
+               torch.from_numpy(r.integers(0, 2, size=(1, N_old, M)).astype(np.uint8)).cuda(),
+               torch.from_numpy(r.integers(0, 2, size=(1, N_old, M)).astype(np.uint8)).cuda())
+        remove = torch.from_numpy(r.random(N_old) < 0.3).cuda()
+    n_prev = 0 if old is None else int((~remove).sum())
+    upd = torch.zeros(N_new, dtype=torch.bool)
+    upd[min(n_prev, N_new):] = True
+    if N_new > 3:
+        upd[1] = True                      # an update inside the kept range overwrites that kept point (reference order)
+        upd[N_new - 2] = False             # and a row that is neither kept nor updated stays empty
+    upd = upd.cuda()
+    new_q = t(1, N_new, Cc)
+    got = hip.update_points(remove, upd, old, new_q, M)
+    # the reference's edit
+    q = torch.zeros(1, N_new, Cc, device="cuda")
+    st = torch.zeros(1, N_new, M, Cc, device="cuda")
+    co = torch.zeros(1, N_new, M, Cc, device="cuda")
+    vi = torch.ones(1, N_new, M, dtype=torch.uint8, device="cuda")
+    me = torch.ones(1, N_new, M, dtype=torch.uint8, device="cuda")
+    if old is not None:
+        keep = ~remove
+        n = min(n_prev, N_new)
+        q[:, :n] = old[0][:, keep][:, :n]
+        st[:, :n] = old[1][:, keep][:, :n]
+        co[:, :n] = old[2][:, keep][:, :n]
+        vi[:, :n] = old[3][:, keep][:, :n]
+        me[:, :n] = old[4][:, keep][:, :n]
+    q[:, upd] = new_q[:, upd]
+    st[:, upd] = 0
+    co[:, upd] = 0
+    vi[:, upd] = 1
+    me[:, upd] = 1
+    for a, b in zip(got, (q, st, co, vi, me)):
+        assert torch.equal(a, b)

@@ -241,6 +241,12 @@ class SplitTensor:
     def float(self) -> torch.Tensor:
         return self.planes[0].float() + self.planes[1].float() / 2048.0
 
+    def clone(self) -> "SplitTensor":
+        t = SplitTensor.__new__(SplitTensor)
+        t.planes = self.planes.clone()
+        t.shape = self.shape
+        return t
+
     def reshape(self, *shape) -> "SplitTensor":
         t = SplitTensor.__new__(SplitTensor)
         t.planes = self.planes.view(2, *shape)

@@ -85,27 +85,39 @@ class LBM(nn.Module):
         times = queries[:, :, 0].long()
         eng = self.transformer.get_engine()
         M = self.memory_size
-        # encode every frame once; sample each query on its own frame (backbone.py:130-172)
+        # Queries are sampled on their own frame (backbone.py:130-172).  The frames on which some query starts are
+        # encoded first and their token buffers kept (a handful of frames: one host read of the distinct start times);
+        # the tracking loop then encodes each remaining frame once into one reused buffer -- O(1) token memory in T
+        # (the reference keeps nothing and re-runs its backbone on every query frame).
         q_init = torch.zeros(B, N, self.embed_dim, device=dev)
-        tokens = []
-        for t in range(T):
+        starts = [int(v) for v in torch.unique(times).tolist() if 0 <= int(v) < T]
+        keep_tokens = len(starts) <= 16
+        cache = {}
+        for t in starts:
             tok = self.backbone.encode_tokens(video[:, t])
-            tokens.append(tok)
             sel = times == t
-            if bool(sel.any()):
-                for b in range(B):
-                    sb = sel[b]
-                    if bool(sb.any()):
-                        q_init[b, sb] = self.backbone.sample_points(tok[b:b + 1], queries[b:b + 1, sb, 1:].contiguous())[0]
+            for b in range(B):
+                idx = torch.nonzero(sel[b]).flatten()
+                if idx.numel():
+                    q_init[b, idx] = self.backbone.sample_points(tok[b:b + 1], queries[b:b + 1, idx, 1:].contiguous())[0]
+            if keep_tokens:
+                ts = self.backbone.last_tokens_split
+                cache[t] = (tok, None if ts is None else ts.clone())
         stream = torch.zeros(B, N, M, self.embed_dim, device=dev)
         coll = torch.zeros(B, N, M, self.embed_dim, device=dev)
         vis_mask = torch.ones(B, N, M, device=dev, dtype=torch.uint8)
         mem_mask = torch.ones(B, N, M, device=dev, dtype=torch.uint8)
         pts, vis = [], []
+        buf = None
         for t in range(T):
+            if t in cache:
+                tok, tok_s = cache.pop(t)
+            else:
+                tok = buf = self.backbone.encode_tokens(video[:, t], buf)
+                tok_s = self.backbone.last_tokens_split
             queried = (times <= t).to(torch.uint8).contiguous()
-            out = eng.step(tokens[t], q_init, stream, coll, vis_mask, mem_mask, ring_head=t % M, queried=queried,
-                           update_state=True, img_hw=(H, W), vis_threshold=self.visibility_treshold)
+            out = eng.step(tok, q_init, stream, coll, vis_mask, mem_mask, ring_head=t % M, queried=queried,
+                           update_state=True, img_hw=(H, W), vis_threshold=self.visibility_treshold, tokens_split=tok_s)
             pts.append(out["coords"])
             vis.append(out["vis"])
         pts = torch.stack(pts, dim=1)

@@ -21,7 +21,7 @@ extern "C" {
 
 typedef void* lbm_stream_t; /* hipStream_t */
 
-#define LBM_HIP_ABI_VERSION 2
+#define LBM_HIP_ABI_VERSION 3
 #define LBM_HIP_MAX_LAYERS 8
 
 int lbm_hip_version(void);
@@ -204,7 +204,10 @@ int lbm_hip_pyramid_s(float* tokens, void* tokens_s, int64_t tokens_plane, int32
 #define LBM_W_LAYER_UPDATE 40
 #define LBM_W_LAYER_RHO_W 54  /* [1,256] reference_rho */
 #define LBM_W_LAYER_RHO_B 55
-#define LBM_W_LAYER_COUNT 56
+#define LBM_W_LAYER_OLG_W 56  /* [48*9 + 1024, 256] LATTICE.OLW stacked on UPDATE.G: both read the stream-attention output, one
+                               * product serves the deformable offsets/weights and the update attention's queries      */
+#define LBM_W_LAYER_OLG_B 57
+#define LBM_W_LAYER_COUNT 58
 /* after the layers, base = n_layers * LBM_W_LAYER_COUNT */
 #define LBM_W_HEAD_OFFSET 0
 #define LBM_W_HEAD_CMEM 12
@@ -219,7 +222,10 @@ int lbm_hip_pyramid_s(float* tokens, void* tokens_s, int64_t tokens_plane, int32
 #define LBM_W_HEAD_VISH_B3 43
 #define LBM_W_HEAD_VPROJ_W 44 /* [(n_layers+3)*256, 256] value_proj of lattice_0..n-1, offset, collision_mem, vis */
 #define LBM_W_HEAD_VPROJ_B 45
-#define LBM_W_HEAD_COUNT 46
+#define LBM_W_HEAD_OL3_W 46   /* [48*9 + 48*4 + 48*9, 256] OFFSET.OLW, CMEM.OLW, VIS.OLW stacked: the three heads' deformable
+                               * offsets/weights are functions of the same final token                                 */
+#define LBM_W_HEAD_OL3_B 47
+#define LBM_W_HEAD_COUNT 48
 
 typedef struct {
   /* geometry */

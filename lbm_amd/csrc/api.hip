@@ -123,7 +123,7 @@ static int build_layout(const lbm_hip_step_desc* d, StepLayout& lay) {
   lay.add("valid", (unsigned long long)lay.R);
   lay.add("idx", (unsigned long long)lay.Q * sizeof(int));
   lay.add("ref", (unsigned long long)lay.Q * 2 * f);
-  lay.add("offlog", (unsigned long long)lay.R * 48 * 16 * f);
+  lay.add("offlog", (unsigned long long)lay.R * (48 * 16 + 1024) * f);      // deformable offsets/weights (+ merged column blocks)
   lay.add("samp", (unsigned long long)lay.Q * LBM_C * f);
   lay.add("la", (unsigned long long)lay.Q * LBM_C * f);
   lay.add("lb", (unsigned long long)lay.Q * LBM_C * f);
@@ -256,8 +256,9 @@ struct Step {
   }
 
   // memory / lattice-update attention block: x_in [R,256] -> x_out [R,256]
+  // U_pre / ldu: the queries u_h, when an earlier merged product already holds them (a column block of pitch ldu)
   int attn_block(int wb, const TV& x_in, const TV& x_out, const float* seq, long long point_stride, int S, int ring_head,
-                 bool masked, const TV* Yn, const TV* seq_tv = nullptr) {
+                 bool masked, const TV* Yn, const TV* seq_tv = nullptr, const float* U_pre = nullptr, long long ldu = 1024) {
     const int km = (int)lay.kmax;
     TV U = view("U", nullptr, 1, 1, 1024);
     TV mbar = view1("mbar", 1, 1, 1024);
@@ -274,9 +275,9 @@ struct Step {
       return linear_ln(hid, 1024, wb + LBM_W_ATTN_F2W, wb + LBM_W_ATTN_F2B, 1, R, 1024, y.f, 1, 1.f, wb + LBM_W_ATTN_LN2G,
                        wb + LBM_W_ATTN_LN2B, x_out, valid, x_in.f, Yn);
     }
-    if (linear(x_in, LBM_C, wb + LBM_W_ATTN_G, wb + LBM_W_ATTN_GB, U, 1024, R, 1024, LBM_C)) return -1;
+    if (U_pre == nullptr && linear(x_in, LBM_C, wb + LBM_W_ATTN_G, wb + LBM_W_ATTN_GB, U, 1024, R, 1024, LBM_C)) return -1;
     AttnArgs a;
-    a.U = U.f; a.seq = seq; a.point_stride = point_stride; a.slot_stride = LBM_C; a.S = S; a.ring_head = ring_head;
+    a.U = U_pre ? U_pre : U.f; a.ldu = U_pre ? ldu : 1024; a.seq = seq; a.point_stride = point_stride; a.slot_stride = LBM_C; a.S = S; a.ring_head = ring_head;
     a.temb = masked ? W(wb + LBM_W_ATTN_TEMB) : nullptr;
     a.mask_a = masked ? d->vis_mask + (long long)lo * d->M : nullptr;
     a.mask_b = masked ? d->mem_mask + (long long)lo * d->M : nullptr;
@@ -291,15 +292,17 @@ struct Step {
   }
 
   // deformable block: token x [R,256] (replicated k times) sampled at ref [R,k,2] -> out [R*k,256]
-  int msda_block(int wb, int vmap, int P, const TV& x, const float* ref, int k, const TV& out) {
+  // ol_pre / ld_ol: this block's offsets/weights, when an earlier merged product already holds them
+  int msda_block(int wb, int vmap, int P, const TV& x, const float* ref, int k, const TV& out, const float* ol_pre = nullptr,
+                 int ld_ol = 0) {
     const int Q = R * k;
     const int km = (int)lay.kmax;
-    TV offlog = view("offlog", nullptr, 1, 1, 48 * 16);
+    TV offlog = view("offlog", nullptr, 1, 1, 48 * 16 + 1024);
     TV samp = view1("samp", km, k, LBM_C);
     TV hid = view1("hid", km, k, 1024);
     TV la = view("la", "la_s", km, k, LBM_C);
     const int ncol = 48 * P;
-    if (linear(x, LBM_C, wb + LBM_W_MSDA_OLW, wb + LBM_W_MSDA_OLB, offlog, ncol, R, ncol, LBM_C)) return -1;
+    if (ol_pre == nullptr && linear(x, LBM_C, wb + LBM_W_MSDA_OLW, wb + LBM_W_MSDA_OLB, offlog, ncol, R, ncol, LBM_C)) return -1;
     MsdaArgs m;
     m.value = buf<float>("value") + (long long)vmap * LBM_C;
     m.ldv = lay.n_vmaps * LBM_C;
@@ -311,7 +314,7 @@ struct Step {
     }
     // a sub-run only exists for B == 1, where its rows all belong to stream 0
     m.B = nsub > 1 ? 1 : d->B; m.N = nsub > 1 ? R : d->N; m.k = k; m.P = P;
-    m.offlog = offlog.f; m.ld_offlog = ncol; m.logit_col = 32 * P;
+    m.offlog = ol_pre ? ol_pre : offlog.f; m.ld_offlog = ol_pre ? ld_ol : ncol; m.logit_col = 32 * P;
     m.ref = ref; m.net_w = (float)d->net_w; m.net_h = (float)d->net_h;
     m.out = samp.f; m.out_s = samp.s; m.out_plane = samp.plane;
     if (msda_sample(m, s)) return -1;
@@ -417,7 +420,14 @@ struct Step {
         return -1;
       }
       // lattice deformable attention on the k regions (transformer.py:316-327)
-      if (msda_block(lw + LBM_W_LAYER_LATTICE, i, d->n_points, tb, rdst, k, lb)) return -1;
+      // the lattice offsets/weights and (k > 1) the update attention's queries are both products of the stream output:
+      // one merged product [R, 48 P + 1024]
+      TV olg = view("offlog", nullptr, 1, 1, 48 * 16 + 1024);
+      const int ncol_ol = 48 * d->n_points;
+      const bool merged = k > 1 && W(lw + LBM_W_LAYER_OLG_W) != nullptr;
+      const int ld_olg = ncol_ol + 1024;
+      if (merged && linear(tb, LBM_C, lw + LBM_W_LAYER_OLG_W, lw + LBM_W_LAYER_OLG_B, olg, ld_olg, R, ld_olg, LBM_C)) return -1;
+      if (msda_block(lw + LBM_W_LAYER_LATTICE, i, d->n_points, tb, rdst, k, lb, merged ? olg.f : nullptr, ld_olg)) return -1;
       if (d->ref_rho[i]) {   // [1,256] read-out, kept on the exact fp32 path in both modes (weights stay fp32)
         GemmArgs g;
         g.X = lb.f; g.ldx = LBM_C; g.W = W(lw + LBM_W_LAYER_RHO_W); g.ldw = LBM_C; g.bias = W(lw + LBM_W_LAYER_RHO_B);
@@ -426,7 +436,9 @@ struct Step {
       }
       // lattice update (transformer.py:330-338)
       const TV& xn = (i & 1) ? x1 : x0;
-      if (attn_block(lw + LBM_W_LAYER_UPDATE, tb, xn, lb.f, (long long)k * LBM_C, k, 0, false, nullptr, &lb)) return -1;
+      if (attn_block(lw + LBM_W_LAYER_UPDATE, tb, xn, lb.f, (long long)k * LBM_C, k, 0, false, nullptr, &lb,
+                     merged ? olg.f + ncol_ol : nullptr, ld_olg))
+        return -1;
       x = xn;
       if (i == d->n_layers - 1 && rdst != ref) {
         if (hipMemcpyAsync(ref, rdst, (size_t)R * 2 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) {
@@ -440,11 +452,16 @@ struct Step {
     float* pred = buf<float>("pred") + (long long)lo * 2;
     TV coll_tok = view("coll_tok", nullptr, 1, 1, LBM_C);
     float* offset = d->offset + (long long)lo * 2;
-    if (msda_block(hb + LBM_W_HEAD_OFFSET, d->n_layers, d->n_points, x, ref, 1, ta)) return -1;
+    // the three heads' deformable offsets/weights are products of the same token: one merged product
+    TV ol3 = view("offlog", nullptr, 1, 1, 48 * 16 + 1024);
+    const int c_off = 0, c_cm = 48 * d->n_points, c_vis = c_cm + 48 * d->n_points_cmem, ld3 = c_vis + 48 * d->n_points;
+    const bool m3 = W(hb + LBM_W_HEAD_OL3_W) != nullptr && ld3 <= 48 * 16 + 1024;
+    if (m3 && linear(x, LBM_C, hb + LBM_W_HEAD_OL3_W, hb + LBM_W_HEAD_OL3_B, ol3, ld3, R, ld3, LBM_C)) return -1;
+    if (msda_block(hb + LBM_W_HEAD_OFFSET, d->n_layers, d->n_points, x, ref, 1, ta, m3 ? ol3.f + c_off : nullptr, ld3)) return -1;
     if (linear(ta, LBM_C, hb + LBM_W_HEAD_OFFH_W0, hb + LBM_W_HEAD_OFFH_B0, hidR, LBM_C, R, LBM_C, LBM_C, ACT_GELU)) return -1;
     if (offset_final(hidR.f, W(hb + LBM_W_HEAD_OFFH_W3), W(hb + LBM_W_HEAD_OFFH_B3), ref, (float)d->stride, offset, pred, R, s)) return -1;
-    if (msda_block(hb + LBM_W_HEAD_CMEM, d->n_layers + 1, d->n_points_cmem, x, pred, 1, coll_tok)) return -1;
-    if (msda_block(hb + LBM_W_HEAD_VIS, d->n_layers + 2, d->n_points, x, ref, 1, ta)) return -1;
+    if (msda_block(hb + LBM_W_HEAD_CMEM, d->n_layers + 1, d->n_points_cmem, x, pred, 1, coll_tok, m3 ? ol3.f + c_cm : nullptr, ld3)) return -1;
+    if (msda_block(hb + LBM_W_HEAD_VIS, d->n_layers + 2, d->n_points, x, ref, 1, ta, m3 ? ol3.f + c_vis : nullptr, ld3)) return -1;
     if (linear(ta, LBM_C, hb + LBM_W_HEAD_VISH_W0, hb + LBM_W_HEAD_VISH_B0, hidR, LBM_C, R, LBM_C, LBM_C, ACT_GELU)) return -1;
     StateFinalArgs f;
     f.vis_hidden = hidR.f; f.w3 = W(hb + LBM_W_HEAD_VISH_W3); f.b3 = W(hb + LBM_W_HEAD_VISH_B3);

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void attn_readout_kernel(AttnArgs a) {
 
   float4 u[LBM_HEADS];
 #pragma unroll
-  for (int hh = 0; hh < LBM_HEADS; ++hh) u[hh] = ld4(a.U + ((long long)row * LBM_HEADS + hh) * LBM_C + lane * 4);
+  for (int hh = 0; hh < LBM_HEADS; ++hh) u[hh] = ld4(a.U + (long long)row * a.ldu + hh * LBM_C + lane * 4);
 
   const float* sp = a.seq + (long long)row * a.point_stride + lane * 4;
   const uint8_t* ma = a.mask_a ? a.mask_a + (long long)row * a.S : nullptr;
@@ -188,7 +188,8 @@ int attn_readout(const AttnArgs& a, hipStream_t stream) {
   LBM_REQUIRE(a.U && a.seq && (a.out || a.out_s), "attn_readout: null argument");
   LBM_REQUIRE(a.S >= 1 && a.S <= 4096, "attn_readout: sequence length %d out of range", a.S);
   LBM_REQUIRE(a.ring_head >= 0 && a.ring_head < a.S, "attn_readout: ring head %d outside [0,%d)", a.ring_head, a.S);
-  LBM_REQUIRE(a.slot_stride % 4 == 0 && a.point_stride % 4 == 0, "attn_readout: strides must be multiples of 4 floats");
+  LBM_REQUIRE(a.slot_stride % 4 == 0 && a.point_stride % 4 == 0 && a.ldu % 4 == 0 && a.ldu >= 4 * LBM_C,
+              "attn_readout: strides must be multiples of 4 floats");
   // algorithmic traffic: the S sequence rows once, 4 per-head queries in, 4 per-head read-outs out, the masks
   ProfScope prof("attn_readout", stream, (double)a.R * a.S * 4.0 * LBM_C * 4,
                  (double)a.R * (4.0 * LBM_C * (a.S + 8) + (a.mask_a ? a.S : 0) + (a.mask_b ? a.S : 0)));

@@ -6,6 +6,7 @@ namespace lbm {
 
 struct AttnArgs {
   const float* U = nullptr;        // [R, 4, 256]  per-head key-space queries u_h = Wk_hᵀ(Wq_h x + bq_h) / 8
+  long long ldu = 4 * LBM_C;       // row pitch of U in floats (wider when U is a column block of a merged product)
   const float* seq = nullptr;      // per-point sequence, element (r, j, c) at seq + r*point_stride + j*slot_stride + c
   long long point_stride = 0;
   long long slot_stride = LBM_C;

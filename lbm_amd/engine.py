@@ -291,6 +291,10 @@ class TrackerWeights:
                      ly.lattice_update_ffn, ly.lattice_update_norm2)
             put(base + k["LBM_W_LAYER_RHO_W"], ly.reference_rho.weight)
             put(base + k["LBM_W_LAYER_RHO_B"], ly.reference_rho.bias)
+            # products that share their input are merged: lattice offsets/weights and the update attention's queries
+            lat, upd = base + k["LBM_W_LAYER_LATTICE"], base + k["LBM_W_LAYER_UPDATE"]
+            put(base + k["LBM_W_LAYER_OLG_W"], torch.cat([self.tensors[lat + k["LBM_W_MSDA_OLW"]], self.tensors[upd + k["LBM_W_ATTN_G"]]], 0))
+            put(base + k["LBM_W_LAYER_OLG_B"], torch.cat([self.tensors[lat + k["LBM_W_MSDA_OLB"]], self.tensors[upd + k["LBM_W_ATTN_GB"]]], 0))
             self.corr_mix += [float(v) for v in ly.corr_conv.weight.detach().flatten().tolist()]
             self.corr_bias.append(float(ly.corr_conv.bias.detach().item()))
             vw.append(ly.lattice_attention.value_proj.weight)
@@ -308,6 +312,9 @@ class TrackerWeights:
         for att in (tr.offset_layer, tr.collision_mem_layer, tr.vis_layer):
             vw.append(att.value_proj.weight)
             vb.append(att.value_proj.bias)
+        heads3 = [hb_ + k[n] for n in ("LBM_W_HEAD_OFFSET", "LBM_W_HEAD_CMEM", "LBM_W_HEAD_VIS")]
+        put(hb_ + k["LBM_W_HEAD_OL3_W"], torch.cat([self.tensors[h + k["LBM_W_MSDA_OLW"]] for h in heads3], 0))
+        put(hb_ + k["LBM_W_HEAD_OL3_B"], torch.cat([self.tensors[h + k["LBM_W_MSDA_OLB"]] for h in heads3], 0))
         put(hb_ + k["LBM_W_HEAD_VPROJ_W"], torch.cat(vw, 0))
         put(hb_ + k["LBM_W_HEAD_VPROJ_B"], torch.cat(vb, 0))
         # which table entries are matrices of a dense contraction (they get split planes)

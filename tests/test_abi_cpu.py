@@ -34,10 +34,12 @@ def test_weight_table_constants_are_consistent():
     assert k["LBM_W_LAYER_LATTICE"] == 2 * k["LBM_W_ATTN_COUNT"]
     assert k["LBM_W_LAYER_UPDATE"] == k["LBM_W_LAYER_LATTICE"] + k["LBM_W_MSDA_COUNT"]
     assert k["LBM_W_LAYER_RHO_W"] == k["LBM_W_LAYER_UPDATE"] + k["LBM_W_ATTN_COUNT"]
-    assert k["LBM_W_LAYER_COUNT"] == k["LBM_W_LAYER_RHO_B"] + 1
+    assert k["LBM_W_LAYER_OLG_W"] == k["LBM_W_LAYER_RHO_B"] + 1
+    assert k["LBM_W_LAYER_COUNT"] == k["LBM_W_LAYER_OLG_B"] + 1
     assert k["LBM_W_HEAD_CMEM"] == k["LBM_W_MSDA_COUNT"] and k["LBM_W_HEAD_VIS"] == 2 * k["LBM_W_MSDA_COUNT"]
     assert k["LBM_W_HEAD_OFFH_W0"] == 3 * k["LBM_W_MSDA_COUNT"]
-    assert k["LBM_W_HEAD_COUNT"] == k["LBM_W_HEAD_VPROJ_B"] + 1
+    assert k["LBM_W_HEAD_OL3_W"] == k["LBM_W_HEAD_VPROJ_B"] + 1
+    assert k["LBM_W_HEAD_COUNT"] == k["LBM_W_HEAD_OL3_B"] + 1
 
 
 def test_host_side_validation_needs_no_gpu():

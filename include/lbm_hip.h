@@ -288,6 +288,13 @@ typedef struct {
    *     `sub_index` < 4 naming this range's private scratch region; phase 2 calls of disjoint ranges may run
    *     concurrently on different streams once phase 1 has completed.                                          */
   int32_t phase, row_lo, row_count, sub_index;
+  /* optional conveniences, each saving the caller (and the GPU) a tiny launch per frame:
+   * query_split: split twin of `query` (lbm_hip_split_planes; lo plane B*N*256 elements further) for precision >= 1 --
+   *   the query never changes between point-set updates, so it need not be re-split every frame;
+   * vis_flag [B,N] bytes = sigmoid(vis) > vis_threshold; rho_prob [B,N] = sigmoid(rho)   (lbm_online.py:148-149)       */
+  const void* query_split;
+  uint8_t* vis_flag;
+  float* rho_prob;
 } lbm_hip_step_desc;
 
 /* Add / remove tracked points without a host round trip.  Replaces the state edit of LBM_online.update

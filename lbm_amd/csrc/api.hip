@@ -357,7 +357,12 @@ struct Step {
     const float* query = d->query + (long long)lo * LBM_C;
     TV xq = view(nullptr, "q_s", 1, 1, LBM_C);
     xq.f = const_cast<float*>(query);
-    if (split && split_planes(query, xq.s, (char*)xq.s + 2 * xq.plane, RC, s)) return -1;
+    if (split && d->query_split) {          // the caller keeps the twin: planes of the whole [Rfull, 256] query
+      xq.s = (char*)const_cast<void*>(d->query_split) + (long long)lo * LBM_C * 2;
+      xq.plane = Rfull * LBM_C;
+    } else if (split && split_planes(query, xq.s, (char*)xq.s + 2 * xq.plane, RC, s)) {
+      return -1;
+    }
     TV x0 = view("x0", "x0_s", 1, 1, LBM_C), x1 = view("x1", "x1_s", 1, 1, LBM_C), ta = view("ta", "ta_s", 1, 1, LBM_C),
        tb = view("tb", "tb_s", 1, 1, LBM_C);
     TV qn = view1("qn", 1, 1, LBM_C);
@@ -440,12 +445,7 @@ struct Step {
                      merged ? olg.f + ncol_ol : nullptr, ld_olg))
         return -1;
       x = xn;
-      if (i == d->n_layers - 1 && rdst != ref) {
-        if (hipMemcpyAsync(ref, rdst, (size_t)R * 2 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) {
-          set_error("step: ref copy failed");
-          return -1;
-        }
-      }
+      if (i == d->n_layers - 1) ref = rdst;     // k = 1: the heads read the single cell centre where top-k left it
     }
     // ---- heads (transformer.py:103-149); `ref` now holds the last layer's single cell centre per point ----
     TV hidR = view("hidR", nullptr, 1, 1, LBM_C);
@@ -475,6 +475,8 @@ struct Step {
     f.M = M; f.ring_head = d->ring_head; f.vis_threshold = d->vis_threshold;
     f.vis = d->vis + lo; f.rho = d->rho + lo; f.ref = ref; f.offset = offset; f.coords = d->coords ? d->coords + (long long)lo * 2 : nullptr;
     f.net_w = (float)d->net_w; f.net_h = (float)d->net_h; f.img_w = d->img_w; f.img_h = d->img_h;
+    f.vis_flag = d->vis_flag ? d->vis_flag + lo : nullptr;
+    f.rho_prob = d->rho_prob ? d->rho_prob + lo : nullptr;
     f.R = R;
     return state_final(f, s);
   }

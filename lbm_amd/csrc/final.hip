@@ -58,8 +58,10 @@ __global__ __launch_bounds__(256) void state_final_kernel(StateFinalArgs a) {
   if (lane == 0) {
     a.vis[row] = vis;
     a.rho[row] = rho;
+    const float sg = 1.0f / (1.0f + expf(-vis));
+    if (a.vis_flag) a.vis_flag[row] = sg > a.vis_threshold ? 1 : 0;
+    if (a.rho_prob) a.rho_prob[row] = 1.0f / (1.0f + expf(-rho));
     if (a.vis_mask) {
-      const float sg = 1.0f / (1.0f + expf(-vis));
       a.vis_mask[(long long)row * a.M + a.ring_head] = sg < a.vis_threshold ? 1 : 0;   // lbm_online.py:146
       a.mem_mask[(long long)row * a.M + a.ring_head] = queried ? 0 : 1;                 // lbm_online.py:145
     }

@@ -27,6 +27,8 @@ struct StateFinalArgs {
   const float* ref = nullptr;         // [R,2] last-layer cell centre (network px)
   const float* offset = nullptr;      // [R,2]
   float* coords = nullptr;            // optional [R,2] in caller pixels
+  uint8_t* vis_flag = nullptr;        // optional [R]: sigmoid(vis) > vis_threshold
+  float* rho_prob = nullptr;          // optional [R]: sigmoid(rho)
   float net_w = 0, net_h = 0, img_w = 0, img_h = 0;
   int R = 0;
 };

@@ -132,11 +132,15 @@ __global__ __launch_bounds__(256) void corr_maps_kernel(CorrMapArgs a) {
     const int p = (int)(cell % P0);
     const int y = p / a.w, x = p % a.w;
     const float* tb = a.tok + (long long)b * a.L * LBM_C + lane * 4;
-    const float* ib = a.inv + (long long)b * a.L;
+    // 1 / max(|row|, 1e-12) (F.normalize eps) of a row this wave holds, 4 channels per lane: computed here instead of by
+    // a launch of its own (every coarse row is re-normalised by the cells it feeds: 13 wave sums per cell)
+    auto inv_of = [](const float4 q) {
+      return 1.0f / fmaxf(sqrtf(wave_sum(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w)), 1e-12f);
+    };
     float4 lv[4];
     {
-      const float s = ib[p];
       const float4 v = ld4(tb + (long long)p * LBM_C);
+      const float s = inv_of(v);
       lv[0] = make_float4(v.x * s, v.y * s, v.z * s, v.w * s);
     }
     int start = P0;
@@ -149,9 +153,9 @@ __global__ __launch_bounds__(256) void corr_maps_kernel(CorrMapArgs a) {
       up_coeff(x, l, wl, x0, x1, lx0, lx1);
       const int t00 = start + y0 * wl + x0, t01 = start + y0 * wl + x1;
       const int t10 = start + y1 * wl + x0, t11 = start + y1 * wl + x1;
-      const float s00 = ib[t00], s01 = ib[t01], s10 = ib[t10], s11 = ib[t11];
       const float4 v00 = ld4(tb + (long long)t00 * LBM_C), v01 = ld4(tb + (long long)t01 * LBM_C);
       const float4 v10 = ld4(tb + (long long)t10 * LBM_C), v11 = ld4(tb + (long long)t11 * LBM_C);
+      const float s00 = inv_of(v00), s01 = inv_of(v01), s10 = inv_of(v10), s11 = inv_of(v11);
       float4 r;
       r.x = ly0 * (lx0 * (v00.x * s00) + lx1 * (v01.x * s01)) + ly1 * (lx0 * (v10.x * s10) + lx1 * (v11.x * s11));
       r.y = ly0 * (lx0 * (v00.y * s00) + lx1 * (v01.y * s01)) + ly1 * (lx0 * (v10.y * s10) + lx1 * (v11.y * s11));
@@ -179,19 +183,13 @@ __global__ __launch_bounds__(256) void corr_maps_kernel(CorrMapArgs a) {
 
 int corr_maps(const float* tokens, float* inv_norm, float* F, const float* wmix_host, int n_layers, int B, int h, int w,
               bool split, hipStream_t stream) {
-  LBM_REQUIRE(tokens && inv_norm && F && wmix_host, "corr_maps: null argument");
+  LBM_REQUIRE(tokens && F && wmix_host, "corr_maps: null argument");
   LBM_REQUIRE(n_layers >= 1 && n_layers <= 8, "corr_maps: n_layers=%d out of range", n_layers);
   LBM_REQUIRE(B > 0 && h % 8 == 0 && w % 8 == 0, "corr_maps: grid %dx%d must be a multiple of 8", h, w);
   const int P0 = h * w;
   const int L = P0 + P0 / 4 + P0 / 16 + P0 / 64;
-  long long rows = (long long)B * L;
-  long long blocks = (rows + 3) / 4;
-  if (blocks > 16384) blocks = 16384;
-  {
-    ProfScope prof("inv_norm", stream, 0.0, 4.0 * LBM_C * rows);
-    hipLaunchKernelGGL(inv_norm_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, tokens, inv_norm, rows);
-  }
-  if (check_launch("inv_norm")) return -1;
+  long long blocks;
+  (void)inv_norm;   // (kept in the signature: the norms are now computed inside the map kernel)
   CorrMapArgs a;
   a.tok = tokens; a.inv = inv_norm; a.F = F; a.n_layers = n_layers; a.B = B; a.h = h; a.w = w; a.L = L; a.split = split ? 1 : 0;
   for (int i = 0; i < 8; ++i)

@@ -356,6 +356,7 @@ class TrackEngine:
         self.cfg = cfg
         self.w = weights
         self.dev = weights.device
+        self._q_split = None                          # (key, SplitTensor): split twin of the last query tensor seen
         self._ws: Dict[int, torch.Tensor] = {}       # workspace per slot (a pipelined caller alternates two)
         self._ws_key: Dict[int, tuple] = {}
 
@@ -429,7 +430,19 @@ class TrackEngine:
             d.row_lo, d.row_count = int(rows[0]), int(rows[1])
         if out is None:
             out = {"coords": torch.empty(B, N, 2, device=dev), "vis": torch.empty(B, N, device=dev),
-                   "rho": torch.empty(B, N, device=dev), "offset": torch.empty(B, N, 2, device=dev)}
+                   "rho": torch.empty(B, N, device=dev), "offset": torch.empty(B, N, 2, device=dev),
+                   "vis_flag": torch.empty(B, N, device=dev, dtype=torch.bool), "rho_prob": torch.empty(B, N, device=dev)}
+        if "vis_flag" in out:
+            d.vis_flag, d.rho_prob = out["vis_flag"].data_ptr(), out["rho_prob"].data_ptr()
+        if d.precision >= 1 and N > 0 and phase != 1:
+            # the query only changes at point-set updates: keep its split twin instead of re-splitting it every frame
+            key = (query.data_ptr(), query._version, tuple(query.shape))
+            if self._q_split is None or self._q_split[0] != key:
+                qs = hip.SplitTensor(tuple(query.shape), dev)
+                hip._check(hip.load().lbm_hip_split_planes(hip._p(query), qs.hi, qs.planes[1].data_ptr(), query.numel(), hip._stream()),
+                           "lbm_hip_split_planes")
+                self._q_split = (key, qs)
+            d.query_split = self._q_split[1].hi
         if want_memory:
             out["stream"] = torch.empty(B, N, 256, device=dev)
             out["collision"] = torch.empty(B, N, 256, device=dev)

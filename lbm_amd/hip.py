@@ -82,7 +82,8 @@ class StepDesc(C.Structure):
                 ("ref_rho", C.c_void_p * MAX_LAYERS), ("corr", C.c_void_p * MAX_LAYERS),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_uint64),
                 ("aux_streams", C.c_void_p * 3), ("n_aux_streams", C.c_int32),
-                ("phase", C.c_int32), ("row_lo", C.c_int32), ("row_count", C.c_int32), ("sub_index", C.c_int32)]
+                ("phase", C.c_int32), ("row_lo", C.c_int32), ("row_count", C.c_int32), ("sub_index", C.c_int32),
+                ("query_split", C.c_void_p), ("vis_flag", C.c_void_p), ("rho_prob", C.c_void_p)]
 
 
 class ProfileEntry(C.Structure):

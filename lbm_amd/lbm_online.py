@@ -236,7 +236,7 @@ class LBM_online(LBM):
                 if tokens is not None:
                     tokens.copy_(tok)
                     tok = tokens
-                return out["coords"], torch.sigmoid(out["vis"]) > self.visibility_treshold, torch.sigmoid(out["rho"]), tok
+                return out["coords"], out["vis_flag"], out["rho_prob"], tok
         if self._pipe is not None:      # the encoder's scratch is shared: never run it on two streams at once
             torch.cuda.current_stream().wait_stream(self._pipe["stream"])
         if self.use_graph and frames.is_cuda and self.B * self.N <= self.graph_max_rows and self.N > 0:
@@ -254,7 +254,7 @@ class LBM_online(LBM):
         self._head = (self._head + 1) % self.memory_size
         self.t += 1
         self.last_logits = (out["vis"], out["rho"])
-        return out["coords"], torch.sigmoid(out["vis"]) > self.visibility_treshold, torch.sigmoid(out["rho"]), tok
+        return out["coords"], out["vis_flag"], out["rho_prob"], tok
 
     def _forward_graph(self, frames: torch.Tensor):
         """Replay (capturing on first use) the HIP graph of this frame step; None = not available, run eagerly."""

@@ -297,6 +297,14 @@ typedef struct {
   float* rho_prob;
 } lbm_hip_step_desc;
 
+/* Tail of the encoder (backbone.py:53-65, 181-193 and transformer.py:58-69 in one pass): the 1x1 projections, the
+ * bilinear up-sampling and the fusion 1x1 + BatchNorm are all linear, so the caller multiplies each feature level by
+ * (fusion o projection) at its own resolution (q1 [B,h*w,256] with the folded bias, q2 [B,h*w/4,256], q3 [B,h*w/16,256])
+ * and this kernel forms tokens = GELU(q1 + up2(q2) + up4(q3)) + pos for level 0, the three pooled levels, and (tokens_s
+ * != NULL) the split twin of the whole buffer.                                                                  */
+int lbm_hip_encoder_tail(const float* q1, const float* q2, const float* q3, const float* pos, float* tokens, void* tokens_s,
+                         int64_t tokens_plane, int32_t B, int32_t h, int32_t w, lbm_stream_t stream);
+
 /* Add / remove tracked points without a host round trip.  Replaces the state edit of LBM_online.update
  * (lbm_online.py:84-110): the old rows with remove_mask == 0 move, in order, to the front of the new state
  * (query, both memories in their physical ring order -- the caller's ring head is unchanged --, both masks); rows with

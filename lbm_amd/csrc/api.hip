@@ -700,6 +700,11 @@ int lbm_hip_pyramid_s(float* tokens, void* tokens_s, int64_t tokens_plane, int32
   return pyramid_pool(tokens, B, h, w, (hipStream_t)stream, tokens_s, tokens_plane);
 }
 
+int lbm_hip_encoder_tail(const float* q1, const float* q2, const float* q3, const float* pos, float* tokens, void* tokens_s,
+                         int64_t tokens_plane, int32_t B, int32_t h, int32_t w, lbm_stream_t stream) {
+  return encoder_tail(q1, q2, q3, pos, tokens, B, h, w, (hipStream_t)stream, tokens_s, tokens_plane);
+}
+
 int lbm_hip_update_points(const uint8_t* remove_mask, int32_t N_old, const uint8_t* update_mask, int32_t N_new, int32_t M,
                           const float* old_query, const float* old_stream, const float* old_coll, const uint8_t* old_vis,
                           const uint8_t* old_mem, const float* new_query, float* query, float* stream_mem, float* coll_mem,

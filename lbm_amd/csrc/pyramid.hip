@@ -25,13 +25,35 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
   }
 }
 
+// bilinear source index/weights of F.interpolate(align_corners=False) from size `in` to `in << lvl`
+__device__ __forceinline__ void up_coeff(int dst, int lvl, int in, int& i0, int& i1, float& l0, float& l1) {
+  const float scale = 1.0f / (float)(1 << lvl);
+  float src = scale * ((float)dst + 0.5f) - 0.5f;
+  if (src < 0.f) src = 0.f;
+  i0 = (int)src;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+  l0 = 1.0f - l1;
+}
+
 // One workgroup per 8x8 block of level-0 cells, one wave per 4x4 quadrant, lane = 4 channels: the 16 level-0 rows of
 // a quadrant are loaded once (all loads in flight), giving its four level-1 cells and its level-2 cell in registers;
 // the level-3 cell is the mean of the four quadrant sums (through LDS).  With `toks` the split twin of every row
 // touched, level 0 included, is emitted on the way.  (The first version walked each output cell's s x s window with
 // dependent loads: 40 us at one 96x128 frame, all of it the 64-load chains of the 192 level-3 cells.)
+// TAIL: level 0 does not exist yet -- it is formed here as GELU(q1 + up2(q2) + up4(q3)) + pos from the three feature
+// levels already multiplied by (fusion o projection) at their own resolution (backbone.py:53-63 with the 1x1
+// projections, the bilinear up-sampling and the fusion 1x1 + BatchNorm commuted: all linear), and written out as well.
+struct TailArgs {
+  const float* q1;    // [B, h*w, 256]   (bias of the folded fusion already added)
+  const float* q2;    // [B, (h/2)*(w/2), 256]
+  const float* q3;    // [B, (h/4)*(w/4), 256]
+  const float* pos;   // [h*w, 256] or null
+};
+
+template <bool TAIL>
 __global__ __launch_bounds__(256) void pyramid_pool_kernel(float* __restrict__ tok, int B, int h, int w, int L, void* toks,
-                                                           long long toks_plane) {
+                                                           long long toks_plane, TailArgs ta) {
   __shared__ float4 part[4][64];
   const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int bw = w >> 3, bh = h >> 3;
@@ -43,10 +65,53 @@ __global__ __launch_bounds__(256) void pyramid_pool_kernel(float* __restrict__ t
   float* base = tok + (long long)b * L * LBM_C + lane * 4;
   const long long sbase = (long long)b * L * LBM_C + lane * 4;
   float4 v[4][4];
+  if constexpr (!TAIL) {
 #pragma unroll
-  for (int dy = 0; dy < 4; ++dy)
+    for (int dy = 0; dy < 4; ++dy)
 #pragma unroll
-    for (int dx = 0; dx < 4; ++dx) v[dy][dx] = ld4(base + (long long)((y0 + dy) * w + x0 + dx) * LBM_C);
+      for (int dx = 0; dx < 4; ++dx) v[dy][dx] = ld4(base + (long long)((y0 + dy) * w + x0 + dx) * LBM_C);
+  } else {
+    const int h2 = h >> 1, w2 = w >> 1, h4 = h >> 2, w4 = w >> 2;
+    const float* q1 = ta.q1 + (long long)b * P0 * LBM_C + lane * 4;
+    const float* q2 = ta.q2 + (long long)b * h2 * w2 * LBM_C + lane * 4;
+    const float* q3 = ta.q3 + (long long)b * h4 * w4 * LBM_C + lane * 4;
+    auto bil = [](const float* q, int wl, int ya, int yb, int xa, int xb, float lya, float lyb, float lxa, float lxb) {
+      const float4 v00 = ld4(q + (long long)(ya * wl + xa) * LBM_C), v01 = ld4(q + (long long)(ya * wl + xb) * LBM_C);
+      const float4 v10 = ld4(q + (long long)(yb * wl + xa) * LBM_C), v11 = ld4(q + (long long)(yb * wl + xb) * LBM_C);
+      float4 r;
+      r.x = lya * (lxa * v00.x + lxb * v01.x) + lyb * (lxa * v10.x + lxb * v11.x);
+      r.y = lya * (lxa * v00.y + lxb * v01.y) + lyb * (lxa * v10.y + lxb * v11.y);
+      r.z = lya * (lxa * v00.z + lxb * v01.z) + lyb * (lxa * v10.z + lxb * v11.z);
+      r.w = lya * (lxa * v00.w + lxb * v01.w) + lyb * (lxa * v10.w + lxb * v11.w);
+      return r;
+    };
+#pragma unroll
+    for (int dy = 0; dy < 4; ++dy) {
+      int ya, yb, yc, yd;
+      float lya, lyb, lyc, lyd;
+      up_coeff(y0 + dy, 1, h2, ya, yb, lya, lyb);
+      up_coeff(y0 + dy, 2, h4, yc, yd, lyc, lyd);
+#pragma unroll
+      for (int dx = 0; dx < 4; ++dx) {
+        int xa, xb, xc, xd;
+        float lxa, lxb, lxc, lxd;
+        up_coeff(x0 + dx, 1, w2, xa, xb, lxa, lxb);
+        up_coeff(x0 + dx, 2, w4, xc, xd, lxc, lxd);
+        const long long cell = (long long)(y0 + dy) * w + x0 + dx;
+        const float4 a1 = ld4(q1 + cell * LBM_C);
+        const float4 a2 = bil(q2, w2, ya, yb, xa, xb, lya, lyb, lxa, lxb);
+        const float4 a3 = bil(q3, w4, yc, yd, xc, xd, lyc, lyd, lxc, lxd);
+        float4 t = make_float4(gelu_erf(a1.x + a2.x + a3.x), gelu_erf(a1.y + a2.y + a3.y), gelu_erf(a1.z + a2.z + a3.z),
+                               gelu_erf(a1.w + a2.w + a3.w));
+        if (ta.pos) {
+          const float4 p = ld4(ta.pos + cell * LBM_C + lane * 4);
+          t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w;
+        }
+        v[dy][dx] = t;
+        st4(base + cell * LBM_C, t);
+      }
+    }
+  }
   if (toks) {
 #pragma unroll
     for (int dy = 0; dy < 4; ++dy)
@@ -89,8 +154,22 @@ int pyramid_pool(float* tokens, int B, int h, int w, hipStream_t stream, void* t
   const long long blocks = (long long)B * (h / 8) * (w / 8);
   LBM_REQUIRE(blocks < 0x7fffffffLL, "pyramid_pool: too many blocks");
   ProfScope prof("pyramid_pool", stream, 0.0, 4.0 * LBM_C * B * ((double)P0 + (L - P0)) * (toks ? 2.0 : 1.0));
-  hipLaunchKernelGGL(pyramid_pool_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, tokens, B, h, w, L, toks, toks_plane);
+  hipLaunchKernelGGL(pyramid_pool_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, tokens, B, h, w, L, toks, toks_plane,
+                     TailArgs{});
   return check_launch("pyramid_pool");
+}
+
+int encoder_tail(const float* q1, const float* q2, const float* q3, const float* pos, float* tokens, int B, int h, int w,
+                 hipStream_t stream, void* toks, long long toks_plane) {
+  LBM_REQUIRE(q1 && q2 && q3 && tokens && B > 0 && h % 8 == 0 && w % 8 == 0, "encoder_tail: bad arguments (grid %dx%d)", h, w);
+  const int P0 = h * w;
+  const int L = P0 + P0 / 4 + P0 / 16 + P0 / 64;
+  const long long blocks = (long long)B * (h / 8) * (w / 8);
+  LBM_REQUIRE(blocks < 0x7fffffffLL, "encoder_tail: too many blocks");
+  ProfScope prof("encoder_tail", stream, 0.0, 4.0 * LBM_C * B * ((double)P0 * (1.0 + 0.25 + 0.0625 + (pos ? 1.0 : 0.0)) + (double)L * (toks ? 2.0 : 1.0)));
+  TailArgs ta{q1, q2, q3, pos};
+  hipLaunchKernelGGL(pyramid_pool_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream, tokens, B, h, w, L, toks, toks_plane, ta);
+  return check_launch("encoder_tail");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -111,17 +190,6 @@ struct CorrMapArgs {
   int n_layers, B, h, w, L;
   int split;            // 1: F is written as split f16 planes, per layer [hi: B*P0*256][lo: B*P0*256]
 };
-
-// bilinear source index/weights of F.interpolate(align_corners=False) from size `in` to `in << lvl`
-__device__ __forceinline__ void up_coeff(int dst, int lvl, int in, int& i0, int& i1, float& l0, float& l1) {
-  const float scale = 1.0f / (float)(1 << lvl);
-  float src = scale * ((float)dst + 0.5f) - 0.5f;
-  if (src < 0.f) src = 0.f;
-  i0 = (int)src;
-  i1 = i0 + (i0 < in - 1 ? 1 : 0);
-  l1 = src - (float)i0;
-  l0 = 1.0f - l1;
-}
 
 __global__ __launch_bounds__(256) void corr_maps_kernel(CorrMapArgs a) {
   const int lane = threadIdx.x & 63;

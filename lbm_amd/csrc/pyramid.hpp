@@ -16,6 +16,8 @@ int corr_maps(const float* tokens, float* inv_norm, float* F, const float* wmix_
 int topk_rows(const float* corr, long long ld, int P, int k, int rows, int grid_w, int stride_px, int* idx_out,
               float* ref_out, float* val_out, hipStream_t stream);
 
+int encoder_tail(const float* q1, const float* q2, const float* q3, const float* pos, float* tokens, int B, int h, int w,
+                 hipStream_t stream, void* toks = nullptr, long long toks_plane = 0);
 int topk_candidates(const float* cand_v, const int* cand_i, int n_cand, int P, int k, int rows, int grid_w, int stride_px, int* idx_out,
                     float* ref_out, float* val_out, hipStream_t stream);
 void topk_force_mode(int m);   // tuning: 1 = the per-lane-list kernels for every shape

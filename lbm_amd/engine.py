@@ -107,13 +107,22 @@ class EncoderWeights:
                     down = _Conv(_pack_conv(wd), bd, 1, blk.stride, 0, dev)
                 self.blocks.append((_Conv(_pack_conv(w1), b1, 3, blk.stride, 1, dev), _Conv(_pack_conv(w2), b2, 3, 1, 1, dev), down))
         f32 = lambda t: t.to(dev, torch.float32).contiguous()
-        self.proj = [(f32(_f64(p.weight).flatten(1)), f32(_f64(p.bias))) for p in (bb.proj1, bb.proj2, bb.proj3)]
-        self.proj_s = [hip.SplitWeight(pw) for pw, _ in self.proj]
+        # backbone.py:53-63: proj_i (1x1) -> bilinear up-sampling -> concat -> fusion 1x1 -> BatchNorm -> GELU.  Everything
+        # before the GELU is linear and the bilinear weights sum to one, so each level is multiplied by
+        # (BN o fusion)[:, 64 i : 64 i + 64] . proj_i at its OWN resolution (folded in float64) and the three 256-channel
+        # maps are summed after up-sampling (lbm_hip_encoder_tail): no 64-channel intermediates, no 192-channel concat,
+        # 12288 x 256 x 192 of fusion flops become 12288 x 256 x 64 + two small products.
         fw, fb = _fold_bn(bb.fusion[0].weight, bb.fusion[1])
         scale = _f64(bb.fusion[1].weight) / torch.sqrt(_f64(bb.fusion[1].running_var) + bb.fusion[1].eps)
         fb = fb + _f64(bb.fusion[0].bias) * scale
-        self.fusion_w, self.fusion_b = f32(fw.flatten(1)), f32(fb)
-        self.fusion_ws = hip.SplitWeight(self.fusion_w)
+        fw = _f64(fw).flatten(1)                                            # (256, 192)
+        self.lvl_w, bias = [], _f64(fb).clone()
+        for i, p in enumerate((bb.proj1, bb.proj2, bb.proj3)):
+            blk = fw[:, 64 * i: 64 * (i + 1)]                               # (256, 64)
+            self.lvl_w.append(f32(blk @ _f64(p.weight).flatten(1)))        # (256, C_i)
+            bias = bias + blk @ _f64(p.bias)
+        self.lvl_b = f32(bias)
+        self.lvl_ws = [hip.SplitWeight(wt) for wt in self.lvl_w]
         self._scratch = None
         self.tokens_split: Optional[hip.SplitTensor] = None     # split twin of the last encode() output
         self._own_split: Optional[hip.SplitTensor] = None
@@ -148,16 +157,10 @@ class EncoderWeights:
             y = c2(t, True, idn)
             if i % 2 == 1:
                 feats.append(y)
-        ps = []
-        for f, (pw, pb) in zip(feats, self.proj):
-            ps.append(hip.linear(f.view(-1, f.shape[-1]), pw, pb))
-        cat = hip.upcat(ps[0], ps[1], ps[2], B, self.h, self.w)
+        qs = [hip.linear(f.view(-1, f.shape[-1]), wt, self.lvl_b if i == 0 else None) for i, (f, wt) in enumerate(zip(feats, self.lvl_w))]
         if out is None:
             out = torch.empty(B, self.L, 256, device=self.dev, dtype=torch.float32)
-        hip.linear_batched(cat, self.fusion_w, out, bias=self.fusion_b, act=1, res=self.pos if add_pos else None,
-                           strides=(self.P0 * 192, 0, 0, self.L * 256, 0), M=self.P0, N=256, K=192, ldx=192, ldw=192,
-                           ldy=256, ldres=256, batch=B)
-        hip.pyramid(out, self.h, self.w)
+        hip.encoder_tail(qs[0], qs[1], qs[2], self.pos if add_pos else None, out, None, self.h, self.w)
         return out
 
 
@@ -175,24 +178,17 @@ class EncoderWeights:
             y, ys = c2.split(ts, True, idn, scratch=self._scratch, planes=self.planes)
             if i % 2 == 1:
                 feats.append(ys)
-        ps = []
-        for f, pw, (_, pb) in zip(feats, self.proj_s, self.proj):
-            ps.append(hip.linear_ss(f.reshape(-1, f.shape[-1]), pw, pb, planes=self.planes)[0])
-        cat = hip.upcat_s(ps[0], ps[1], ps[2], B, self.h, self.w)
+        qs = [hip.linear_ss(f.reshape(-1, f.shape[-1]), wt, self.lvl_b if i == 0 else None, planes=self.planes)[0]
+              for i, (f, wt) in enumerate(zip(feats, self.lvl_ws))]
         if out is None:
             out = torch.empty(B, self.L, 256, device=self.dev, dtype=torch.float32)
-        P0 = self.P0
-        hip.linear_ss_raw(A=cat.hi, a_plane=cat.plane, B=self.fusion_ws.hi, b_plane=self.fusion_ws.planes[0].numel(),
-                          bias=self.fusion_b.data_ptr(), Y=out.data_ptr(), res=self.pos.data_ptr() if add_pos else None,
-                          M=P0, N=256, K=192, lda=192, ldb=192, ldy=256, ldres=256, res_div=1, res_mod=0, res_scale=1.0, act=1,
-                          batch=B, sA=P0 * 192, sB=0, sBias=0, sY=self.L * 256, sR=0, planes=self.planes)
         target, self._split_target = self._split_target, None
         if target is None:      # the encoder's own twin; a caller-owned one (pipelined slots) is never reused for another frame
             if self._own_split is None or self._own_split.shape != (B, self.L, 256):
                 self._own_split = hip.SplitTensor((B, self.L, 256), self.dev)
             target = self._own_split
         self.tokens_split = target
-        hip.pyramid_s(out, target, self.h, self.w)
+        hip.encoder_tail(qs[0], qs[1], qs[2], self.pos if add_pos else None, out, target, self.h, self.w)
         return out
 
 

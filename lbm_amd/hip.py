@@ -27,7 +27,7 @@ EXPORTS = (
     "lbm_hip_track_step", "lbm_hip_step_workspace_offset", "lbm_hip_conv2d_nhwc", "lbm_hip_maxpool3x3s2_nhwc",
     "lbm_hip_profile_begin", "lbm_hip_profile_end", "lbm_hip_split_planes", "lbm_hip_debug_set", "lbm_hip_linear_ss",
     "lbm_hip_conv2d_nhwc_ss", "lbm_hip_maxpool3x3s2_nhwc_s", "lbm_hip_upcat_s", "lbm_hip_pyramid_s",
-    "lbm_hip_update_points",
+    "lbm_hip_update_points", "lbm_hip_encoder_tail",
 )
 
 
@@ -138,6 +138,7 @@ def load() -> C.CDLL:
     lib.lbm_hip_preprocess.argtypes = [C.c_void_p, C.c_int64, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p]
     lib.lbm_hip_upcat.argtypes = [C.c_void_p] * 4 + [C.c_int32] * 3 + [C.c_void_p]
     lib.lbm_hip_sample_queries.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p]
+    lib.lbm_hip_encoder_tail.argtypes = [C.c_void_p] * 6 + [C.c_int64] + [C.c_int32] * 3 + [C.c_void_p]
     lib.lbm_hip_update_points.argtypes = ([C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 13)
     lib.lbm_hip_step_workspace_bytes.argtypes = [C.POINTER(StepDesc)]
     lib.lbm_hip_track_step.argtypes = [C.POINTER(StepDesc), C.c_void_p]
@@ -324,6 +325,15 @@ def upcat_s(p1, p2, p3, B, h, w) -> "SplitTensor":
     outs = SplitTensor((B * h * w, 192), p1.device)
     _check(load().lbm_hip_upcat_s(_p(p1), _p(p2), _p(p3), None, outs.hi, outs.plane, B, h, w, _stream()), "lbm_hip_upcat_s")
     return outs
+
+
+def encoder_tail(q1: torch.Tensor, q2: torch.Tensor, q3: torch.Tensor, pos: Optional[torch.Tensor], tokens: torch.Tensor,
+                 tokens_s: Optional["SplitTensor"], h: int, w: int) -> None:
+    """tokens level 0 = GELU(q1 + up2(q2) + up4(q3)) + pos, levels 1..3 pooled, split twin emitted (lbm_hip_encoder_tail)."""
+    _require_gpu()
+    _check(load().lbm_hip_encoder_tail(_p(q1), _p(q2), _p(q3), _p(pos), _p(tokens), tokens_s.hi if tokens_s is not None else None,
+                                       tokens_s.plane if tokens_s is not None else 0, tokens.shape[0], h, w, _stream()),
+           "lbm_hip_encoder_tail")
 
 
 def pyramid_s(tokens: torch.Tensor, tokens_s: "SplitTensor", h: int, w: int) -> None:

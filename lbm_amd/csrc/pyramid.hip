@@ -52,32 +52,34 @@ struct TailArgs {
 };
 
 template <bool TAIL>
-__global__ __launch_bounds__(256) void pyramid_pool_kernel(float* __restrict__ tok, int B, int h, int w, int L, void* toks,
-                                                           long long toks_plane, TailArgs ta) {
-  __shared__ float4 part[4][64];
+__global__ __launch_bounds__(1024) void pyramid_pool_kernel(float* __restrict__ tok, int B, int h, int w, int L, void* toks,
+                                                            long long toks_plane, TailArgs ta) {
+  // 16 waves per 8x8 block: wave q owns the 2x2 cells at (2 (q / 4), 2 (q % 4)) -- all of its loads are independent and
+  // in flight together -- and produces their level-1 cell; the 2x2 sums meet in LDS for levels 2 (waves 0..3) and 3.
+  __shared__ float4 part[16][64];
   const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int bw = w >> 3, bh = h >> 3;
   const int P0 = h * w;
   const int b = blockIdx.x / (bh * bw);
   const int rem = blockIdx.x - b * (bh * bw);
   const int by = rem / bw, bx = rem - by * bw;
-  const int y0 = by * 8 + (q >> 1) * 4, x0 = bx * 8 + (q & 1) * 4;
+  const int y0 = by * 8 + (q >> 2) * 2, x0 = bx * 8 + (q & 3) * 2;
   float* base = tok + (long long)b * L * LBM_C + lane * 4;
   const long long sbase = (long long)b * L * LBM_C + lane * 4;
-  float4 v[4][4];
+  float4 v[2][2];
   if constexpr (!TAIL) {
 #pragma unroll
-    for (int dy = 0; dy < 4; ++dy)
+    for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
-      for (int dx = 0; dx < 4; ++dx) v[dy][dx] = ld4(base + (long long)((y0 + dy) * w + x0 + dx) * LBM_C);
+      for (int dx = 0; dx < 2; ++dx) v[dy][dx] = ld4(base + (long long)((y0 + dy) * w + x0 + dx) * LBM_C);
   } else {
     const int h2 = h >> 1, w2 = w >> 1, h4 = h >> 2, w4 = w >> 2;
     const float* q1 = ta.q1 + (long long)b * P0 * LBM_C + lane * 4;
     const float* q2 = ta.q2 + (long long)b * h2 * w2 * LBM_C + lane * 4;
     const float* q3 = ta.q3 + (long long)b * h4 * w4 * LBM_C + lane * 4;
-    auto bil = [](const float* q, int wl, int ya, int yb, int xa, int xb, float lya, float lyb, float lxa, float lxb) {
-      const float4 v00 = ld4(q + (long long)(ya * wl + xa) * LBM_C), v01 = ld4(q + (long long)(ya * wl + xb) * LBM_C);
-      const float4 v10 = ld4(q + (long long)(yb * wl + xa) * LBM_C), v11 = ld4(q + (long long)(yb * wl + xb) * LBM_C);
+    auto bil = [](const float* qq, int wl, int ya, int yb, int xa, int xb, float lya, float lyb, float lxa, float lxb) {
+      const float4 v00 = ld4(qq + (long long)(ya * wl + xa) * LBM_C), v01 = ld4(qq + (long long)(ya * wl + xb) * LBM_C);
+      const float4 v10 = ld4(qq + (long long)(yb * wl + xa) * LBM_C), v11 = ld4(qq + (long long)(yb * wl + xb) * LBM_C);
       float4 r;
       r.x = lya * (lxa * v00.x + lxb * v01.x) + lyb * (lxa * v10.x + lxb * v11.x);
       r.y = lya * (lxa * v00.y + lxb * v01.y) + lyb * (lxa * v10.y + lxb * v11.y);
@@ -86,13 +88,13 @@ __global__ __launch_bounds__(256) void pyramid_pool_kernel(float* __restrict__ t
       return r;
     };
 #pragma unroll
-    for (int dy = 0; dy < 4; ++dy) {
+    for (int dy = 0; dy < 2; ++dy) {
       int ya, yb, yc, yd;
       float lya, lyb, lyc, lyd;
       up_coeff(y0 + dy, 1, h2, ya, yb, lya, lyb);
       up_coeff(y0 + dy, 2, h4, yc, yd, lyc, lyd);
 #pragma unroll
-      for (int dx = 0; dx < 4; ++dx) {
+      for (int dx = 0; dx < 2; ++dx) {
         int xa, xb, xc, xd;
         float lxa, lxb, lxc, lxd;
         up_coeff(x0 + dx, 1, w2, xa, xb, lxa, lxb);
@@ -114,9 +116,9 @@ __global__ __launch_bounds__(256) void pyramid_pool_kernel(float* __restrict__ t
   }
   if (toks) {
 #pragma unroll
-    for (int dy = 0; dy < 4; ++dy)
+    for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
-      for (int dx = 0; dx < 4; ++dx) st4_split(toks, toks_plane, sbase + (long long)((y0 + dy) * w + x0 + dx) * LBM_C, v[dy][dx]);
+      for (int dx = 0; dx < 2; ++dx) st4_split(toks, toks_plane, sbase + (long long)((y0 + dy) * w + x0 + dx) * LBM_C, v[dy][dx]);
   }
   auto add = [](float4 a, const float4 c) { a.x += c.x; a.y += c.y; a.z += c.z; a.w += c.w; return a; };
   auto mul = [](const float4 a, float f) { return make_float4(a.x * f, a.y * f, a.z * f, a.w * f); };
@@ -124,26 +126,24 @@ __global__ __launch_bounds__(256) void pyramid_pool_kernel(float* __restrict__ t
     st4(base + cell * LBM_C, o);
     if (toks) st4_split(toks, toks_plane, sbase + cell * LBM_C, o);
   };
-  // level 1: 2x2 windows, summed in row-major order
-  const int w1 = w >> 1, w2 = w >> 2, w3 = w >> 3;
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const float4 s4 = add(add(add(v[2 * i][2 * j], v[2 * i][2 * j + 1]), v[2 * i + 1][2 * j]), v[2 * i + 1][2 * j + 1]);
-      put(P0 + (long long)((y0 >> 1) + i) * w1 + (x0 >> 1) + j, mul(s4, 0.25f));
-    }
-  // level 2: the 4x4 window, row-major
-  float4 s16 = v[0][0];
-#pragma unroll
-  for (int t = 1; t < 16; ++t) s16 = add(s16, v[t >> 2][t & 3]);
-  put(P0 + (P0 >> 2) + (long long)(y0 >> 2) * w2 + (x0 >> 2), mul(s16, 1.0f / 16.0f));
-  // level 3: the four quadrant sums
-  part[q][lane] = s16;
+  const int w1 = w >> 1, w2l = w >> 2, w3 = w >> 3;
+  // level 1: this wave's 2x2 window, row-major
+  const float4 s4 = add(add(add(v[0][0], v[0][1]), v[1][0]), v[1][1]);
+  put(P0 + (long long)(y0 >> 1) * w1 + (x0 >> 1), mul(s4, 0.25f));
+  part[q][lane] = s4;
   __syncthreads();
-  if (q == 0) {
-    const float4 s64 = add(add(add(part[0][lane], part[1][lane]), part[2][lane]), part[3][lane]);
-    put(P0 + (P0 >> 2) + (P0 >> 4) + (long long)by * w3 + bx, mul(s64, 1.0f / 64.0f));
+  if (q < 4) {
+    // level 2: quadrant q = (q / 2, q % 2) of the block, the four 2x2 sums inside it
+    const int qy = q >> 1, qx = q & 1;
+    const int w0 = (qy * 2) * 4 + qx * 2;            // wave holding its top-left 2x2
+    const float4 s16 = add(add(add(part[w0][lane], part[w0 + 1][lane]), part[w0 + 4][lane]), part[w0 + 5][lane]);
+    put(P0 + (P0 >> 2) + (long long)(by * 2 + qy) * w2l + bx * 2 + qx, mul(s16, 1.0f / 16.0f));
+    if (q == 0) {
+      float4 s64 = part[0][lane];
+#pragma unroll
+      for (int t = 1; t < 16; ++t) s64 = add(s64, part[t][lane]);
+      put(P0 + (P0 >> 2) + (P0 >> 4) + (long long)by * w3 + bx, mul(s64, 1.0f / 64.0f));
+    }
   }
 }
 
@@ -154,7 +154,7 @@ int pyramid_pool(float* tokens, int B, int h, int w, hipStream_t stream, void* t
   const long long blocks = (long long)B * (h / 8) * (w / 8);
   LBM_REQUIRE(blocks < 0x7fffffffLL, "pyramid_pool: too many blocks");
   ProfScope prof("pyramid_pool", stream, 0.0, 4.0 * LBM_C * B * ((double)P0 + (L - P0)) * (toks ? 2.0 : 1.0));
-  hipLaunchKernelGGL(pyramid_pool_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, tokens, B, h, w, L, toks, toks_plane,
+  hipLaunchKernelGGL(pyramid_pool_kernel<false>, dim3((unsigned)blocks), dim3(1024), 0, stream, tokens, B, h, w, L, toks, toks_plane,
                      TailArgs{});
   return check_launch("pyramid_pool");
 }
@@ -168,7 +168,7 @@ int encoder_tail(const float* q1, const float* q2, const float* q3, const float*
   LBM_REQUIRE(blocks < 0x7fffffffLL, "encoder_tail: too many blocks");
   ProfScope prof("encoder_tail", stream, 0.0, 4.0 * LBM_C * B * ((double)P0 * (1.0 + 0.25 + 0.0625 + (pos ? 1.0 : 0.0)) + (double)L * (toks ? 2.0 : 1.0)));
   TailArgs ta{q1, q2, q3, pos};
-  hipLaunchKernelGGL(pyramid_pool_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream, tokens, B, h, w, L, toks, toks_plane, ta);
+  hipLaunchKernelGGL(pyramid_pool_kernel<true>, dim3((unsigned)blocks), dim3(1024), 0, stream, tokens, B, h, w, L, toks, toks_plane, ta);
   return check_launch("encoder_tail");
 }
 
@@ -200,15 +200,12 @@ __global__ __launch_bounds__(256) void corr_maps_kernel(CorrMapArgs a) {
     const int p = (int)(cell % P0);
     const int y = p / a.w, x = p % a.w;
     const float* tb = a.tok + (long long)b * a.L * LBM_C + lane * 4;
-    // 1 / max(|row|, 1e-12) (F.normalize eps) of a row this wave holds, 4 channels per lane: computed here instead of by
-    // a launch of its own (every coarse row is re-normalised by the cells it feeds: 13 wave sums per cell)
-    auto inv_of = [](const float4 q) {
-      return 1.0f / fmaxf(sqrtf(wave_sum(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w)), 1e-12f);
-    };
+    // (the row norms come from inv_norm_kernel: computing them here, 13 wave sums per cell, cost 9 us to save a 5 us launch)
+    const float* ib = a.inv + (long long)b * a.L;
     float4 lv[4];
     {
       const float4 v = ld4(tb + (long long)p * LBM_C);
-      const float s = inv_of(v);
+      const float s = ib[p];
       lv[0] = make_float4(v.x * s, v.y * s, v.z * s, v.w * s);
     }
     int start = P0;
@@ -223,7 +220,7 @@ __global__ __launch_bounds__(256) void corr_maps_kernel(CorrMapArgs a) {
       const int t10 = start + y1 * wl + x0, t11 = start + y1 * wl + x1;
       const float4 v00 = ld4(tb + (long long)t00 * LBM_C), v01 = ld4(tb + (long long)t01 * LBM_C);
       const float4 v10 = ld4(tb + (long long)t10 * LBM_C), v11 = ld4(tb + (long long)t11 * LBM_C);
-      const float s00 = inv_of(v00), s01 = inv_of(v01), s10 = inv_of(v10), s11 = inv_of(v11);
+      const float s00 = ib[t00], s01 = ib[t01], s10 = ib[t10], s11 = ib[t11];
       float4 r;
       r.x = ly0 * (lx0 * (v00.x * s00) + lx1 * (v01.x * s01)) + ly1 * (lx0 * (v10.x * s10) + lx1 * (v11.x * s11));
       r.y = ly0 * (lx0 * (v00.y * s00) + lx1 * (v01.y * s01)) + ly1 * (lx0 * (v10.y * s10) + lx1 * (v11.y * s11));
@@ -251,13 +248,19 @@ __global__ __launch_bounds__(256) void corr_maps_kernel(CorrMapArgs a) {
 
 int corr_maps(const float* tokens, float* inv_norm, float* F, const float* wmix_host, int n_layers, int B, int h, int w,
               bool split, hipStream_t stream) {
-  LBM_REQUIRE(tokens && F && wmix_host, "corr_maps: null argument");
+  LBM_REQUIRE(tokens && inv_norm && F && wmix_host, "corr_maps: null argument");
   LBM_REQUIRE(n_layers >= 1 && n_layers <= 8, "corr_maps: n_layers=%d out of range", n_layers);
   LBM_REQUIRE(B > 0 && h % 8 == 0 && w % 8 == 0, "corr_maps: grid %dx%d must be a multiple of 8", h, w);
   const int P0 = h * w;
   const int L = P0 + P0 / 4 + P0 / 16 + P0 / 64;
-  long long blocks;
-  (void)inv_norm;   // (kept in the signature: the norms are now computed inside the map kernel)
+  long long rows = (long long)B * L;
+  long long blocks = (rows + 3) / 4;
+  if (blocks > 16384) blocks = 16384;
+  {
+    ProfScope prof("inv_norm", stream, 0.0, 4.0 * LBM_C * rows);
+    hipLaunchKernelGGL(inv_norm_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, tokens, inv_norm, rows);
+  }
+  if (check_launch("inv_norm")) return -1;
   CorrMapArgs a;
   a.tok = tokens; a.inv = inv_norm; a.F = F; a.n_layers = n_layers; a.B = B; a.h = h; a.w = w; a.L = L; a.split = split ? 1 : 0;
   for (int i = 0; i < 8; ++i)

@@ -15,10 +15,11 @@ from collections import defaultdict
 
 def short(name: str) -> str:
     """rocprof kernel name -> the launcher's ProfScope name used by bench.py."""
-    m = re.search(r"gemm_ss_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (true|false), (true|false)(?:, (\d+))?>", name)
+    m = re.search(r"gemm_ss_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (true|false), (true|false)(?:, (\d+))?(?:, (\d+))?>", name)
     if m:
-        bm, bn, wm, wn, st, conv, full, topk = m.groups()
-        base = "conv_ss" if conv == "true" else ("gemm_ss_topk" + topk if topk not in (None, "0") else "gemm_ss")
+        bm, bn, wm, wn, st, conv, full, topk, npl = m.groups()
+        sfx = "h" if npl == "1" else "s"
+        base = "conv_s" + sfx if conv == "true" else ("gemm_ss_topk" + topk if topk not in (None, "0") else "gemm_s" + sfx)
         return f"{base}{'_full' if full == 'true' else ''}<{bm},{bn},{wm},{wn},{st}>"
     m = re.search(r"lbm::(\w+?)_kernel", name)
     return m.group(1) if m else name[:60]

@@ -110,8 +110,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--pipeline", action="store_true",
-                    help="enqueue frame t+1's encoder on a second HIP stream before frame t's per-point phase "
-                         "(LBM_online.prefetch); measured SLOWER on MI355X, see DESIGN.md, so off by default")
+                    help="force the frame pipeline on (LBM_online.prefetch: frame t+1's encoder on a second HIP stream beside "
+                         "frame t's per-point phase); default: decided by a short probe during warm-up")
+    ap.add_argument("--no-pipeline", action="store_true", help="force strictly serial frames")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -157,7 +158,17 @@ def main():
         model.init_streams(pts, video[:, 0].contiguous())
         frames = [video[:, 1 + i].contiguous() for i in range(nfr)]
         tok = None
-        pipeline = args.pipeline or os.environ.get("LBM_AMD_PIPELINE", "0") == "1"
+        # Frame pipeline (LBM_online.prefetch): encoder + value/correlation maps of frame t+1 on a second HIP stream beside
+        # the per-point phase of frame t; bit-identical tracks (tests/test_hip_parity.py).  Whether two queues of one process
+        # overlap or get in each other's way differs from box to box (measured both: -11 % and +30 % step time), so unless
+        # forced (--pipeline / --no-pipeline, LBM_AMD_PIPELINE=0|1) both forms are timed on a few warm-up frames and the
+        # faster one runs the timed steps.
+        forced = os.environ.get("LBM_AMD_PIPELINE")
+        if args.pipeline:
+            forced = "1"
+        if args.no_pipeline:
+            forced = "0"
+        pipeline = forced == "1"
 
         def run(n):
             # n complete frames: n encoder passes and n tracker passes, all inside the caller's barriers.  Pipelined, the
@@ -174,6 +185,23 @@ def main():
                     out = model.online_forward_batch(frames[i % nfr], tokens=tok)
                     tok = out[3]
             return out
+
+        probe = {}
+        if forced is None:
+            run(3)
+            for mode in (False, True, False, True):
+                pipeline, tok = mode, None
+                barrier()
+                tp = time.perf_counter()
+                run(12)
+                torch.cuda.synchronize()
+                probe[mode] = min(probe.get(mode, 1e9), (time.perf_counter() - tp) / 12)
+            pipeline = probe[True] < 0.97 * probe[False]
+            if dist is not None:      # one decision for the whole job (rank 0's)
+                flag = torch.tensor([1 if pipeline else 0], device=device if args.backend == "nccl" else "cpu")
+                dist.broadcast(flag, 0)
+                pipeline = bool(flag.item())
+            tok = None
 
         run(args.warmup)
         barrier()
@@ -226,7 +254,9 @@ def main():
             "config": {"workload": f"{args.workload}: {wl['desc']}", "streams_per_gpu": B, "points_per_stream": N,
                        "memory_size": wl["M"], "frame": [wl["H"], wl["W"]],
                        "frame_pipeline": ("encoder + value/correlation maps of frame t+1 on a second HIP stream, overlapping the "
-                                          "per-point phase of frame t" if pipeline else "none (serial frames)"),
+                                          "per-point phase of frame t" if pipeline else "none (serial frames)") +
+                                         (f"; chosen by warm-up probe: serial {1e3 * probe[False]:.3f} ms/frame, pipelined "
+                                          f"{1e3 * probe[True]:.3f} ms/frame" if probe else "; forced"),
                        "precision": PRECISION_LABEL[os.environ.get("LBM_AMD_PRECISION", "split")], "parallelism": f"streams x{world} (no collective in the step)"},
             "p50_latency_ms": statistics.median(lat),
         }

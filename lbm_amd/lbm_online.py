@@ -179,7 +179,9 @@ class LBM_online(LBM):
         maps, about half of a frame's GPU time with one stream of ~1000 points -- is enqueued on a second HIP stream
         into the other of two token / workspace slots, so it overlaps the per-point chain of the current frame, whose
         ~120 small dependent launches leave most of the 256 CUs idle.  Results are identical to the unpipelined call
-        (same kernels on the same data); only the time at which they run changes.  The caller must not modify
+        (same kernels on the same data); only the time at which they run changes.  Measured on MI355X boxes: -10 % step
+        time at 1024 points on most, +30 % on one (two queues of one process getting in each other's way), so a caller
+        that cares should time both forms on its machine, as bench.py does.  The caller must not modify
         ``frames`` until the matching online_forward call has been made.  No counterpart in the reference, whose
         frame loop is strictly serial (lbm_online.py:114-158, tools/benchmark_torch.py:71-76)."""
         if self.query is None or not frames.is_cuda:

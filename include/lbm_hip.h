@@ -308,7 +308,9 @@ int lbm_hip_encoder_tail(const float* q1, const float* q2, const float* q3, cons
 /* Add / remove tracked points without a host round trip.  Replaces the state edit of LBM_online.update
  * (lbm_online.py:84-110): the old rows with remove_mask == 0 move, in order, to the front of the new state
  * (query, both memories in their physical ring order -- the caller's ring head is unchanged --, both masks); rows with
- * update_mask != 0 take new_query[row] and an empty memory (every slot ignored); all other rows are zero / ignored.
+ * update_mask != 0 take new_query[row] -- a surviving row re-planted this way keeps its memories, as in the reference
+ * (lbm_online.py:93-98), a row past the survivors starts with an empty memory (every slot ignored); rows that are
+ * neither are zero / ignored.
  * The kept-row count is computed and consumed on the device (the reference's .item() / nonzero syncs are gone).
  * scratch: N_old + 1 int32.  The new state must not alias the old one.                                          */
 int lbm_hip_update_points(const uint8_t* remove_mask, int32_t N_old, const uint8_t* update_mask, int32_t N_new, int32_t M,

@@ -125,7 +125,9 @@ __global__ __launch_bounds__(256) void update_gather_kernel(UpdatePointsArgs a) 
   if (d >= a.N_new) return;
   const int n_prev = a.scratch[a.N_old];
   const bool fresh = a.update_mask[d] != 0;
-  const int s = (!fresh && d < n_prev) ? a.scratch[d] : -1;          // old row that moves here, if any
+  // old row that moves here, if any.  A surviving row whose point is re-planted (fresh, d < n_prev) gets the new query but
+  // KEEPS its memories, as the reference does (lbm_online.py:93-98 copy the memories of every surviving row)
+  const int s = d < n_prev ? a.scratch[d] : -1;
   const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 q = zero;
   if (fresh) q = ld4(a.new_query + (long long)d * LBM_C + lane * 4);

@@ -55,8 +55,8 @@ class LBM_online(LBM):
         self._pf = {}               # frame key -> slot, for the (at most two) frames encoded ahead
         self.pipelined_frames = 0   # frames whose encoder ran ahead on the encoder stream
         if with_obj_tracker:
-            raise NotImplementedError("the object-tracking association layer (object_tracker.py) is outside the hot path "
-                                      "(SURVEY §8 f.1); update() below provides the add/remove-points primitive it drives")
+            from .object_tracker import LBMObjTracker
+            self.objtracker = LBMObjTracker(args)
 
     # ---- logical (oldest-first) views of the ring state, reference layout (1|B, N, M, ...) ----
     def _logical(self, x: Optional[torch.Tensor]):
@@ -301,8 +301,32 @@ class LBM_online(LBM):
         self.last_logits = (vis, rho)
         return out["coords"].clone(), torch.sigmoid(vis) > self.visibility_treshold, torch.sigmoid(rho), self._g_tok
 
+    @torch.no_grad()
     def online_forward_obj(self, frame, bboxes, scores, labels):
-        raise NotImplementedError("object tracking (lbm_online.py:160-200, object_tracker.py) is outside the hot path")
+        """lbm_online.py:160-200 — one frame of object tracking: track the points planted in the known objects, associate
+        this frame's detections (bboxes (n,4) xyxy frame px, scores (n,), labels (n,); None = no detector run on this
+        frame) with the tracklets through those points, then plant / drop points as the tracklets changed.
+        Returns (coords, visibility, pred_track_instances) -- the point predictions are those made BEFORE the update."""
+        coords = visibility = tok = pred_track_instances = None
+        if self.N > 0:
+            coords, visibility, _, tok = self.online_forward_batch(frame)
+            coords, visibility = coords[0], visibility[0]
+        if bboxes is not None:
+            # association runs on the host (object_tracker.py header): one copy of the predictions per frame
+            host_coords = None if coords is None else coords.cpu()
+            host_vis = None if visibility is None else visibility.cpu()
+            pred_track_instances = self.objtracker.track(self.t, bboxes, scores, labels, host_coords, host_vis)
+            memo = self.objtracker.memo
+            update_mask = memo[5].flatten()                                   # (M * npt,)  tracklets after the update
+            remove_mask = self.objtracker.points_remove_mask.flatten()        # (M' * npt,) tracklets before the drop
+            query_points = memo[4].reshape(-1, 2)
+            if self.N == 0:          # nothing was tracked yet: this frame has not been encoded
+                self.img_size = frame.shape[-2:]
+                self.device = frame.device
+                tok = self.backbone.encode_tokens(frame)
+            self.update(query_points, tok, update_mask, remove_mask)
+            self.query_points = query_points
+        return coords, visibility, pred_track_instances
 
 
 class LBM_export(LBM):

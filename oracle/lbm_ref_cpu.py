@@ -485,6 +485,50 @@ class RefOnline:
         c[:, 1] = c[:, 1] / g.size[0] * H
         return c, torch.sigmoid(vis[0]) > g.vis_threshold, torch.sigmoid(rho[0]), feat, vis[0], rho[0]
 
+    def update(self, query_points: Tensor, feat: Tensor, update_mask: Tensor, remove_mask: Tensor) -> None:
+        """lbm_online.py:48-112 — rows that survive ``remove_mask`` move to the front with their memories; rows flagged
+        in ``update_mask`` get a query sampled at their point on ``feat`` (their memories are whatever the row holds:
+        fresh for appended rows, the old ones for a re-planted point of a surviving row, lbm_online.py:93-98)."""
+        g = self.g
+        N = query_points.shape[0]
+        n_old = 0 if self.state is None else self.state.query.shape[1]
+        if N > 0:
+            remove_mask = remove_mask[:n_old]
+            n_prev = int((~remove_mask).sum())
+            H, W = self.img_size
+            pts = query_points[update_mask].clone().float()
+            pts[:, 0] = pts[:, 0] / W * g.size[1]
+            pts[:, 1] = pts[:, 1] / H * g.size[0]
+            q_new = sample_queries(feat, pts, g)
+            st = fresh_state(torch.zeros(1, N, g.embed_dim), g)
+            if self.state is not None and n_prev > 0:
+                old = self.state
+                st.query[:, :n_prev] = old.query[:, ~remove_mask]
+                st.query[:, update_mask] = q_new
+                for name in ("collision", "stream", "vis_mask", "mem_mask"):
+                    getattr(st, name)[:, :n_prev] = getattr(old, name)[:, ~remove_mask]
+            else:
+                st.query = q_new.unsqueeze(0)
+            st.t = 0 if self.state is None else self.state.t
+            self.state = st
+        self.n_points = N
+
+    def online_forward_obj(self, frame: Tensor, bboxes, scores, labels, tracker):
+        """lbm_online.py:160-200 — `tracker` is the association object (its own parity is pinned separately against the
+        reference's LBMObjTracker outputs, tests/golden/objtrack_*.npz)."""
+        coords = vis = feat = inst = None
+        n = getattr(self, "n_points", 0 if self.state is None else self.state.query.shape[1])
+        if n > 0:
+            coords, vis, _, feat, _, _ = self.online_forward(frame)
+        if bboxes is not None:
+            inst = tracker.track(0 if self.state is None else self.state.t, bboxes, scores, labels, coords, vis)
+            memo = tracker.memo
+            if n == 0:
+                self.img_size = frame.shape[-2:]
+                feat = encode_frames(self.sd, self.g, frame)
+            self.update(memo[4].reshape(-1, 2), feat, memo[5].flatten(), tracker.points_remove_mask.flatten())
+        return coords, vis, inst
+
 
 def inference(sd: SD, g: Geometry, video: Tensor, queries: Tensor):
     """lbm.py:211-280 — batched loop with per-point query times; queries (B,N,3) = (t, x, y) in

@@ -30,10 +30,21 @@ REF = "/root/reference"
 from oracle import fixtures as fx  # noqa: E402
 
 
+def pin_reference_packages():
+    """The repo carries an import-path twin of the reference's package (``lbm/``, for drop-in callers): make sure the
+    names below resolve to the REFERENCE's directories and nothing else."""
+    for name in [m for m in sys.modules if m == "lbm" or m.startswith("lbm.")]:
+        del sys.modules[name]
+    for name, sub in (("lbm", "lbm"), ("lbm.models", "lbm/models"), ("lbm.models.lbm", "lbm/models/lbm"), ("lbm.utils", "lbm/utils")):
+        pkg = types.ModuleType(name)
+        pkg.__path__ = [os.path.join(REF, sub)]
+        sys.modules[name] = pkg
+
+
 def import_reference():
     if not os.path.isdir(REF):
         raise SystemExit("make_golden.py needs /root/reference (build container only)")
-    sys.path.insert(0, REF)
+    pin_reference_packages()
     msda = importlib.import_module("lbm.models.lbm.msdeformattn")
     mmcv = types.ModuleType("mmcv")
     ops = types.ModuleType("mmcv.ops")
@@ -42,6 +53,8 @@ def import_reference():
     sys.modules["mmcv"], sys.modules["mmcv.ops"] = mmcv, ops
     tr = importlib.import_module("lbm.models.lbm.transformer")
     cu = importlib.import_module("lbm.utils.coord_utils")
+    for m in (msda, tr, cu):
+        assert m.__file__.startswith(REF + "/"), m.__file__
     return msda, tr, cu
 
 
@@ -162,7 +175,8 @@ def gen_coords(cu_mod):
 
 def main():
     msda_mod, tr_mod, cu_mod = import_reference()
-    os.makedirs(fx.GOLDEN_DIR, exist_ok=True)
+    out_dir = sys.argv[1] if len(sys.argv) > 1 else fx.GOLDEN_DIR      # another directory: regenerate and compare by hand
+    os.makedirs(out_dir, exist_ok=True)
     jobs = {
         "step_tiny64": lambda: gen_step(tr_mod, "tiny64"),
         "step_small256": lambda: gen_step(tr_mod, "small256"),
@@ -175,7 +189,7 @@ def main():
     }
     for name, fn in jobs.items():
         d = fn()
-        path = os.path.join(fx.GOLDEN_DIR, name + ".npz")
+        path = os.path.join(out_dir, name + ".npz")
         np.savez_compressed(path, **d)
         print(f"{name}: {len(d)} arrays, {os.path.getsize(path) / 1024:.0f} KiB")
 

@@ -527,6 +527,66 @@ def test_update_adds_and_removes_points_like_the_reference(hip):
             _cmp(c, oc, rtol=0, atol=COORD_TOL)
 
 
+def test_online_forward_obj_against_oracle_composition(hip):
+    """LBM_online.online_forward_obj (lbm_online.py:160-200): detections in, tracklets out, points planted and dropped
+    on the device as the tracklets change.  Against the oracle's restatement of the same loop (CPU encoder + tracker +
+    realloc-and-copy update) driving its own association object with the same detections and the same random draws."""
+    from lbm_amd.config import LBMConfig
+    from lbm_amd.lbm_online import LBM_online
+    from lbm_amd.object_tracker import LBMObjTracker
+    from lbm_amd.synth import synthetic_state_dict, synthetic_video
+    from oracle import objtrack_scenario as sc
+    T, H, W = 12, 120, 160
+    targs = sc.tracker_args("plain")
+    cfg = LBMConfig(input_size=(96, 128), memory_size=4).to_namespace()
+    for k, v in vars(targs).items():
+        setattr(cfg, k, v)
+    model = LBM_online(cfg, with_obj_tracker=True)
+    sd = synthetic_state_dict(model, seed=42)
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda().eval()
+    g = ref.Geometry(size=(96, 128), memory_size=4)
+    video = synthetic_video(T, H, W, seed=15)
+    scen = sc.Scenario(7, n_objects=4, T=T, W=W, H=H)
+    scen.size *= 0.35                                        # boxes sized for a 160 x 120 frame
+    dets = [scen.detections(t) for t in range(T)]
+    dets[5] = None                                           # a frame on which no detector ran (tools/demo_box.py:62)
+    oracle, otr = ref.RefOnline(sd, g), LBMObjTracker(targs)
+    torch.manual_seed(11)
+    want = []
+    with torch.no_grad():
+        for t in range(T):
+            d = dets[t] or (None, None, None)
+            want.append(oracle.online_forward_obj(video[:, t], *[None if a is None else torch.from_numpy(a) for a in d], otr)
+                        + (otr.ids, getattr(oracle, "n_points", 0),
+                           None if oracle.state is None else (oracle.state.query.clone(), oracle.state.mem_mask.clone())))
+    torch.manual_seed(11)
+    births = drops = 0
+    with torch.no_grad():
+        for t in range(T):
+            d = dets[t] or (None, None, None)
+            n_before = model.N
+            c, v, inst = model.online_forward_obj(video[:, t].cuda(), *d)
+            oc, ov, oinst, oids, on, ostate = want[t]
+            assert (c is None) == (oc is None), t
+            if c is not None:
+                assert c.shape == (n_before, 2)
+                _cmp(c, oc, rtol=0, atol=COORD_TOL)
+            if d[0] is None:
+                assert inst is None and oinst is None
+            else:
+                assert inst["instances_id"].tolist() == oinst["instances_id"].tolist(), t
+                assert torch.equal(inst["bboxes"], oinst["bboxes"])
+                births += int((inst["instances_id"] >= 0).sum())
+                drops += int(model.objtracker.points_remove_mask.any())
+            assert model.objtracker.ids == oids and model.N == on == len(oids) * targs.object_points, t
+            if model.N:
+                assert model.query.shape == (1, model.N, 256) and model.stream_dist.shape == (1, model.N, 4, 256)
+                _cmp(model.query, ostate[0], rtol=2e-3, atol=2e-3)
+                assert (model.mem_mask.cpu() == ostate[1]).all()
+    assert births > 10 and drops >= 2 and model.t == oracle.state.t
+
+
 def test_graph_replay_and_point_parallel_streams_match_the_plain_eager_step(hip, monkeypatch):
     """B = 1, N = 1024: the default path (HIP-graph replay per ring head, per-point chain on 4 concurrent streams)
     against the plain single-stream eager path over 15 frames (the ring wraps: M = 12)."""
@@ -682,7 +742,7 @@ def test_reduced_precision_encoder_and_online_tracker(hip):
 @pytest.mark.parametrize("N_old,N_new", [(0, 5), (9, 9), (700, 900), (2500, 1800)])
 def test_update_points_kernel_against_the_reference_edit(hip, N_old, N_new):
     """lbm_hip_update_points against the reference's own sequence of tensor edits (lbm_online.py:84-110): kept rows to
-    the front in order, update_mask rows overwritten with the new samples (also inside the kept range), the rest empty."""
+    the front in order with their memories, update_mask rows given the new query (also inside the kept range), the rest empty."""
     r = np.random.default_rng(N_old + N_new)
     M, Cc = 5, 256
     t = lambda *s: torch.from_numpy(r.normal(size=s).astype(np.float32)).cuda()
@@ -716,10 +776,6 @@ def test_update_points_kernel_against_the_reference_edit(hip, N_old, N_new):
         co[:, :n] = old[2][:, keep][:, :n]
         vi[:, :n] = old[3][:, keep][:, :n]
         me[:, :n] = old[4][:, keep][:, :n]
-    q[:, upd] = new_q[:, upd]
-    st[:, upd] = 0
-    co[:, upd] = 0
-    vi[:, upd] = 1
-    me[:, upd] = 1
+    q[:, upd] = new_q[:, upd]              # only the query: a re-planted surviving row keeps its memories (lbm_online.py:93-98)
     for a, b in zip(got, (q, st, co, vi, me)):
         assert torch.equal(a, b)

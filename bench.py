@@ -235,8 +235,8 @@ def main():
                 p["per_step_us"] = 1e3 * p["total_ms"] / nprof
 
     # results travel over RCCL only here (gather of the last frame's tracks), as the north star asks
-    from lbm_amd.sharding import gather_tracks, max_over_ranks
-    res = torch.cat([coords, vis.float().unsqueeze(-1), rho.unsqueeze(-1)], -1).contiguous()     # (B, N, 4)
+    from lbm_amd.sharding import gather_tracks, max_over_ranks, pack_tracks
+    res = pack_tracks(coords, vis, rho)                                                          # (B, N, 4) records
     if args.backend == "gloo":
         res = res.cpu()
     gathered = gather_tracks(res, B * world, dst=0)

@@ -324,13 +324,18 @@ class TrackerWeights:
         for i, t in enumerate(self.tensors):
             if t is not None and t.dim() == 2 and i not in f32_idx:
                 self.split[i] = hip.SplitWeight(t)
+        self.n = n
+        self.n_layers = n_layers
+        self.device = dev
+        self.build_tables()
+
+    def build_tables(self) -> None:
+        """The three pointer tables of the step descriptor (fp32, hi planes, lo planes) over self.tensors / self.split."""
+        n = self.n
         self.table = (C.c_void_p * n)(*[None if t is None else t.data_ptr() for t in self.tensors])
         self.table_hi = (C.c_void_p * n)(*[(None if t is None else t.data_ptr()) if self.split[i] is None else self.split[i].hi
                                            for i, t in enumerate(self.tensors)])
         self.table_lo = (C.c_void_p * n)(*[None if sw is None else sw.lo for sw in self.split])
-        self.n = n
-        self.n_layers = n_layers
-        self.device = dev
 
 
 class TrackEngine:

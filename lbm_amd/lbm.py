@@ -50,6 +50,16 @@ class LBM(nn.Module):
         self.backbone.set_precision(precision)
         self.transformer.set_precision(precision)
 
+    def save_packed(self, path: str) -> int:
+        """Writes the packed kernel weights of this model as one arena file (lbm_amd/packed.py)."""
+        from .packed import save_packed
+        return save_packed(self, path)
+
+    def load_packed(self, path: str, expect_digest=None) -> dict:
+        """Installs packed kernel weights from an arena file: one read, one host-to-device copy, no folding."""
+        from .packed import load_packed
+        return load_packed(self, path, expect_digest)
+
     # lbm.py:70-87 — resize the past time embeddings by linear interpolation (align_corners=True), keep "now".
     def set_memory_size(self, memory_size: int) -> None:
         for layer in self.transformer.layers:

@@ -55,3 +55,79 @@ def max_over_ranks(value: float, device, group=None) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t.item())
+
+
+# ---- the result record and its file (results wire format) --------------------------------------------
+# One record per point-frame: four fp32 [x, y, visible (0 / 1), rho], 16 bytes -- the payload of the RCCL gather above
+# (one collective for coordinates, visibility and uncertainty together) and, appended frame after frame behind a
+# 40-byte header, the track file a trajectory consumer reads back in the layout of LBM.inference's result
+# (lbm.py:276-280: 'points' (B,T,N,2), 'visibility' (B,T,N)).
+
+TRACK_MAGIC = b"LBMTRK1\n"
+_TRACK_HEADER = "<8sIIIIff8x"        # magic, streams, points, frames, floats per record, frame height, frame width
+
+
+def pack_tracks(coords: torch.Tensor, visible: torch.Tensor, rho: torch.Tensor) -> torch.Tensor:
+    """coords (..., N, 2), visible (..., N) bool, rho (..., N) -> records (..., N, 4) fp32."""
+    return torch.cat([coords.float(), visible.float().unsqueeze(-1), rho.float().unsqueeze(-1)], dim=-1).contiguous()
+
+
+def unpack_tracks(records: torch.Tensor):
+    """records (..., N, 4) -> coords (..., N, 2), visible (..., N) bool, rho (..., N)."""
+    return records[..., :2], records[..., 2] > 0.5, records[..., 3]
+
+
+class TrackWriter:
+    """Appends one (streams, points, 4) record block per frame; the frame count in the header is kept current, so a file
+    cut short by a crash still reads back every complete frame."""
+
+    def __init__(self, path: str, n_streams: int, n_points: int, frame_hw):
+        import struct
+        self._struct = struct
+        self.shape = (int(n_streams), int(n_points), 4)
+        self.hw = (float(frame_hw[0]), float(frame_hw[1]))
+        self.frames = 0
+        self._f = open(path, "wb")
+        self._header()
+
+    def _header(self) -> None:
+        self._f.seek(0)
+        self._f.write(self._struct.pack(_TRACK_HEADER, TRACK_MAGIC, self.shape[0], self.shape[1], self.frames, 4, *self.hw))
+        self._f.seek(0, 2)
+
+    def append(self, records: torch.Tensor) -> None:
+        if tuple(records.shape) != self.shape:
+            raise ValueError(f"expected a {self.shape} record block, got {tuple(records.shape)}")
+        self._f.write(records.detach().to("cpu", torch.float32).contiguous().numpy().tobytes())
+        self.frames += 1
+        self._header()
+
+    def close(self) -> None:
+        self._f.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def read_tracks(path: str) -> dict:
+    """-> {'points': (S,T,N,2), 'visibility': (S,T,N) bool, 'rho': (S,T,N), 'frame_hw': (H, W)}; only complete frames."""
+    import os
+    import struct
+
+    import numpy as np
+    hsize = struct.calcsize(_TRACK_HEADER)
+    with open(path, "rb") as f:
+        head = f.read(hsize)
+    if len(head) < hsize or head[:8] != TRACK_MAGIC:
+        raise ValueError(f"{path}: not a track file")
+    _, S, N, T, rec, H, W = struct.unpack(_TRACK_HEADER, head)
+    if rec != 4:
+        raise ValueError(f"{path}: {rec} floats per record, this build reads 4")
+    T = min(T, (os.path.getsize(path) - hsize) // (S * N * 16)) if S * N else 0
+    data = np.fromfile(path, dtype="<f4", count=T * S * N * 4, offset=hsize).reshape(T, S, N, 4)
+    r = torch.from_numpy(data.copy()).permute(1, 0, 2, 3)
+    pts, vis, rho = unpack_tracks(r)
+    return {"points": pts.contiguous(), "visibility": vis.contiguous(), "rho": rho.contiguous(), "frame_hw": (H, W)}

@@ -83,3 +83,35 @@ def test_indices_to_coords_host_version(golden):
     gold = golden("coords")
     got = indices_to_coords(torch.from_numpy(gold["idx"]), [384, 512], 4)
     assert np.array_equal(got.numpy(), gold["coords"])
+
+
+def test_packed_weight_container_round_trip_and_rejections(tmp_path):
+    """lbm_amd/packed.py container: entries come back bit-equal at 256-byte aligned offsets; truncated,
+    foreign and inconsistent files are refused."""
+    from collections import OrderedDict
+
+    import numpy as np
+    import pytest
+    import torch
+
+    from lbm_amd import packed
+    g = torch.Generator().manual_seed(1)
+    ent = OrderedDict(a=torch.randn(3, 5, generator=g), b=torch.randn(2, 7, 8, generator=g).half(), c=torch.empty(0, 4),
+                      d=torch.randn(1, generator=g))
+    p = str(tmp_path / "w.lbmw")
+    n = packed.write_arena(p, ent, {"k": [1, 2]}, abi=3, source_digest="abc")
+    header, views, arena = packed.read_arena(p)
+    assert header["abi"] == 3 and header["meta"] == {"k": [1, 2]} and header["source_digest"] == "abc" and arena.numel() == n
+    for name, t in ent.items():
+        assert header["entries"][name]["offset"] % packed.ALIGN == 0
+        assert views[name].dtype == t.dtype and torch.equal(views[name], t)
+    raw = open(p, "rb").read()
+    for bad, what in ((raw[:-1], "bytes on disk"), (b"NOTLBMW\n" + raw[8:], "bad magic"), (raw[:40], "truncated")):
+        q = str(tmp_path / "bad.lbmw")
+        open(q, "wb").write(bad)
+        with pytest.raises(packed.PackedFormatError, match=what):
+            packed.read_header(q)
+    sd = {"x": torch.arange(6.).view(2, 3), "y": torch.ones(2)}
+    d0 = packed.state_digest(sd)
+    sd["y"][1] = float(np.nextafter(np.float32(1), np.float32(2)))
+    assert packed.state_digest(sd) != d0 and len(d0) == 64

@@ -587,6 +587,53 @@ def test_online_forward_obj_against_oracle_composition(hip):
     assert births > 10 and drops >= 2 and model.t == oracle.state.t
 
 
+@pytest.mark.parametrize("precision", ["split", "f32"])
+def test_packed_weight_file_restores_bit_identical_tracks(hip, tmp_path, precision):
+    """lbm_amd/packed.py: a model whose kernels read weights restored from the arena file (no folding, one
+    host-to-device copy) tracks bit-identically to the model that packed them from the checkpoint; stale files are refused."""
+    import time
+    from lbm_amd import packed
+    from lbm_amd.config import LBMConfig
+    from lbm_amd.lbm_online import LBM_online
+    from lbm_amd.synth import synthetic_video, grid_queries
+    T, H, W = 5, 240, 320
+    video = synthetic_video(T, H, W, seed=21).cuda()
+    pts = grid_queries(H, W, 8).cuda()
+    a, sd = _online(dict(input_size=(384, 512), memory_size=12), precision=precision)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    a.backbone.packed(), a.transformer.get_engine()
+    torch.cuda.synchronize()
+    t_pack = time.perf_counter() - t0
+    path = str(tmp_path / "lbm.lbmw")
+    nbytes = a.save_packed(path)
+    digest = packed.state_digest(sd)
+    assert packed.read_header(path)[0]["source_digest"] == digest
+    # a second model that never sees the checkpoint's folded form: random parameters of its own, weights from the file
+    b = LBM_online(LBMConfig(input_size=(384, 512), memory_size=12).to_namespace()).cuda().eval()
+    b.set_precision(precision)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    header = b.load_packed(path, expect_digest=digest)
+    torch.cuda.synchronize()
+    t_load = time.perf_counter() - t0
+    print(f"packed weights [{precision}]: {nbytes / 2**20:.1f} MiB; fold+upload {1e3 * t_pack:.0f} ms, load from file {1e3 * t_load:.0f} ms")
+    assert header["meta"]["memory_size"] == 12
+    outs = []
+    with torch.no_grad():
+        for m in (a, b):
+            m.init(pts, video[:, 0])
+            outs.append([m.online_forward(video[:, t])[:3] for t in range(1, T)])
+    for fa, fb in zip(*outs):
+        for x, y in zip(fa, fb):
+            assert torch.equal(x, y)
+    with pytest.raises(packed.PackedFormatError, match="another checkpoint"):
+        b.load_packed(path, expect_digest="0" * 64)
+    c = LBM_online(LBMConfig(input_size=(384, 512), memory_size=20).to_namespace()).cuda().eval()
+    with pytest.raises(packed.PackedFormatError, match="memory_size"):
+        c.load_packed(path)
+
+
 def test_graph_replay_and_point_parallel_streams_match_the_plain_eager_step(hip, monkeypatch):
     """B = 1, N = 1024: the default path (HIP-graph replay per ring head, per-point chain on 4 concurrent streams)
     against the plain single-stream eager path over 15 frames (the ring wraps: M = 12)."""

@@ -62,3 +62,53 @@ def test_two_ranks_gather_tracks_in_stream_order(n_streams):
     want = torch.arange(n_streams, dtype=torch.float32).view(-1, 1, 1, 1) * 1000 + torch.arange(60, dtype=torch.float32).view(1, 3, 5, 4)
     assert torch.equal(got, want)
     assert slow == 2.0
+
+
+def _record_worker(rank, world, port, path, q):
+    from lbm_amd.sharding import TrackWriter, pack_tracks
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        S, T, N = 3, 4, 6
+        lo, hi = split_streams(S, world, rank)
+        g = torch.Generator().manual_seed(5)
+        coords = torch.rand(S, T, N, 2, generator=g) * 100
+        vis = torch.rand(S, T, N, generator=g) > 0.4
+        rho = torch.rand(S, T, N, generator=g)
+        writer = TrackWriter(path, S, N, (480, 854)) if rank == 0 else None
+        for t in range(T):                       # one gather per frame: what a live consumer on rank 0 would see
+            rec = gather_tracks(pack_tracks(coords[lo:hi, t], vis[lo:hi, t], rho[lo:hi, t]), S, dst=0)
+            if rank == 0:
+                writer.append(rec)
+        if rank == 0:
+            writer.close()
+            q.put((coords, vis, rho))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_track_records_through_the_gather_into_the_track_file(tmp_path):
+    """(x, y, visible, rho) records: packed per rank, gathered per frame, appended to the track file, read back in the
+    layout of LBM.inference's result; a file cut inside a frame yields the complete frames."""
+    from lbm_amd.sharding import read_tracks
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    path = str(tmp_path / "tracks.lbmt")
+    procs = [ctx.Process(target=_record_worker, args=(r, 2, port, path, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    coords, vis, rho = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    got = read_tracks(path)
+    assert got["points"].shape == (3, 4, 6, 2) and got["frame_hw"] == (480.0, 854.0)
+    assert torch.equal(got["points"], coords) and torch.equal(got["visibility"], vis) and torch.equal(got["rho"], rho)
+    raw = open(path, "rb").read()
+    open(path, "wb").write(raw[:-20])
+    cut = read_tracks(path)
+    assert cut["points"].shape == (3, 3, 6, 2) and torch.equal(cut["points"], coords[:, :3])
+    open(path, "wb").write(b"garbage")
+    with pytest.raises(ValueError):
+        read_tracks(path)

@@ -21,7 +21,7 @@ extern "C" {
 
 typedef void* lbm_stream_t; /* hipStream_t */
 
-#define LBM_HIP_ABI_VERSION 3
+#define LBM_HIP_ABI_VERSION 4
 #define LBM_HIP_MAX_LAYERS 8
 
 int lbm_hip_version(void);
@@ -181,7 +181,9 @@ int lbm_hip_pyramid_s(float* tokens, void* tokens_s, int64_t tokens_plane, int32
 #define LBM_W_ATTN_LN2B 12
 #define LBM_W_ATTN_HMSUM 13  /* [256,256] sum over the heads of the HM blocks: the whole read-out when the key sequence has
                               * ONE element (soft-max over one key is exactly 1, transformer.py:333 at top-k = 1)        */
-#define LBM_W_ATTN_COUNT 14
+#define LBM_W_ATTN_F1FM 14   /* f16 fragment-major copies of F1W / F2W (lbm_hip_pack_fragment_major) for the fused feed-forward; */
+#define LBM_W_ATTN_F2FM 15   /* optional (NULL: the feed-forward runs as two products)                                        */
+#define LBM_W_ATTN_COUNT 16
 
 #define LBM_W_MSDA_OLW 0    /* [48P,256] sampling_offsets (32P rows) then attention_weights (16P rows) */
 #define LBM_W_MSDA_OLB 1
@@ -195,37 +197,39 @@ int lbm_hip_pyramid_s(float* tokens, void* tokens_s, int64_t tokens_plane, int32
 #define LBM_W_MSDA_F2B 9
 #define LBM_W_MSDA_LN2G 10
 #define LBM_W_MSDA_LN2B 11
-#define LBM_W_MSDA_COUNT 12
+#define LBM_W_MSDA_F1FM 12   /* as LBM_W_ATTN_F1FM / F2FM */
+#define LBM_W_MSDA_F2FM 13
+#define LBM_W_MSDA_COUNT 14
 
 /* per layer i, base = i * LBM_W_LAYER_COUNT */
 #define LBM_W_LAYER_COLL 0
-#define LBM_W_LAYER_STREAM 14
-#define LBM_W_LAYER_LATTICE 28
-#define LBM_W_LAYER_UPDATE 40
-#define LBM_W_LAYER_RHO_W 54  /* [1,256] reference_rho */
-#define LBM_W_LAYER_RHO_B 55
-#define LBM_W_LAYER_OLG_W 56  /* [48*9 + 1024, 256] LATTICE.OLW stacked on UPDATE.G: both read the stream-attention output, one
+#define LBM_W_LAYER_STREAM 16
+#define LBM_W_LAYER_LATTICE 32
+#define LBM_W_LAYER_UPDATE 46
+#define LBM_W_LAYER_RHO_W 62  /* [1,256] reference_rho */
+#define LBM_W_LAYER_RHO_B 63
+#define LBM_W_LAYER_OLG_W 64  /* [48*9 + 1024, 256] LATTICE.OLW stacked on UPDATE.G: both read the stream-attention output, one
                                * product serves the deformable offsets/weights and the update attention's queries      */
-#define LBM_W_LAYER_OLG_B 57
-#define LBM_W_LAYER_COUNT 58
+#define LBM_W_LAYER_OLG_B 65
+#define LBM_W_LAYER_COUNT 66
 /* after the layers, base = n_layers * LBM_W_LAYER_COUNT */
 #define LBM_W_HEAD_OFFSET 0
-#define LBM_W_HEAD_CMEM 12
-#define LBM_W_HEAD_VIS 24
-#define LBM_W_HEAD_OFFH_W0 36 /* offset_head.net.0 [256,256] */
-#define LBM_W_HEAD_OFFH_B0 37
-#define LBM_W_HEAD_OFFH_W3 38 /* offset_head.net.3 [2,256] */
-#define LBM_W_HEAD_OFFH_B3 39
-#define LBM_W_HEAD_VISH_W0 40
-#define LBM_W_HEAD_VISH_B0 41
-#define LBM_W_HEAD_VISH_W3 42
-#define LBM_W_HEAD_VISH_B3 43
-#define LBM_W_HEAD_VPROJ_W 44 /* [(n_layers+3)*256, 256] value_proj of lattice_0..n-1, offset, collision_mem, vis */
-#define LBM_W_HEAD_VPROJ_B 45
-#define LBM_W_HEAD_OL3_W 46   /* [48*9 + 48*4 + 48*9, 256] OFFSET.OLW, CMEM.OLW, VIS.OLW stacked: the three heads' deformable
+#define LBM_W_HEAD_CMEM 14
+#define LBM_W_HEAD_VIS 28
+#define LBM_W_HEAD_OFFH_W0 42 /* offset_head.net.0 [256,256] */
+#define LBM_W_HEAD_OFFH_B0 43
+#define LBM_W_HEAD_OFFH_W3 44 /* offset_head.net.3 [2,256] */
+#define LBM_W_HEAD_OFFH_B3 45
+#define LBM_W_HEAD_VISH_W0 46
+#define LBM_W_HEAD_VISH_B0 47
+#define LBM_W_HEAD_VISH_W3 48
+#define LBM_W_HEAD_VISH_B3 49
+#define LBM_W_HEAD_VPROJ_W 50 /* [(n_layers+3)*256, 256] value_proj of lattice_0..n-1, offset, collision_mem, vis */
+#define LBM_W_HEAD_VPROJ_B 51
+#define LBM_W_HEAD_OL3_W 52   /* [48*9 + 48*4 + 48*9, 256] OFFSET.OLW, CMEM.OLW, VIS.OLW stacked: the three heads' deformable
                                * offsets/weights are functions of the same final token                                 */
-#define LBM_W_HEAD_OL3_B 47
-#define LBM_W_HEAD_COUNT 48
+#define LBM_W_HEAD_OL3_B 53
+#define LBM_W_HEAD_COUNT 54
 
 typedef struct {
   /* geometry */
@@ -304,6 +308,20 @@ typedef struct {
  * != NULL) the split twin of the whole buffer.                                                                  */
 int lbm_hip_encoder_tail(const float* q1, const float* q2, const float* q3, const float* pos, float* tokens, void* tokens_s,
                          int64_t tokens_plane, int32_t B, int32_t h, int32_t w, lbm_stream_t stream);
+
+/* Fragment-major copy of a split weight matrix [N, K] (N % 32 == 0, K % 16 == 0): out[N/32][K/16][2][64][8] f16 -- for every
+ * (32-row block, 16-deep k step) the 64 lanes' MFMA operand fragments of the hi plane, then of the lo plane, contiguous, so
+ * a wave fetches a fragment with one coalesced 16-byte-per-lane load straight into registers.  Packing-time helper
+ * (the reference has no counterpart: its weights stay in nn.Linear layout).                                       */
+int lbm_hip_pack_fragment_major(const void* hi, const void* lo, int32_t N, int32_t K, void* out, lbm_stream_t stream);
+
+/* Feed-forward 256 -> 1024 -> 256 of transformer.py:343-355 (Linear, GELU(erf), Linear) in one launch for few rows:
+ * slabs[c] = GELU(A . F1[128 c : 128 c + 128]^T + b1[...]) . F2[:, 128 c : 128 c + 128]^T, c = 0..7 -- eight partial [M, 256]
+ * outputs (slab_stride floats apart) whose sum, plus the second layer's bias, is the MLP output; the LayerNorm that
+ * follows in every block of the step reduces them (lbm_hip_track_step does exactly that).  A: split planes [M, lda];
+ * F1_fm / F2_fm: lbm_hip_pack_fragment_major of the two weight matrices; planes 2 (fp32-grade) or 1 (hi planes only). */
+int lbm_hip_ffn_slabs(const void* A, int64_t a_plane, int32_t lda, const void* F1_fm, const float* b1, const void* F2_fm, float* slabs,
+                      int64_t slab_stride, int32_t M, int32_t planes, lbm_stream_t stream);
 
 /* Add / remove tracked points without a host round trip.  Replaces the state edit of LBM_online.update
  * (lbm_online.py:84-110): the old rows with remove_mask == 0 move, in order, to the front of the new state

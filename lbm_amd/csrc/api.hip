@@ -60,7 +60,8 @@ ProfScope::~ProfScope() {
 }
 
 // ---- workspace layout of the step --------------------------------------------------------------
-static constexpr unsigned long long Step_kSlabRows = 8192;
+static constexpr unsigned long long Step_kSlabRows = 16384;
+
 
 struct StepLayout {
   long long R, Q, L, P0, kmax;
@@ -148,6 +149,8 @@ static int build_layout(const lbm_hip_step_desc* d, StepLayout& lay) {
 
 // A tensor view used by the step: fp32 rows and/or the same values as split f16 planes (hi at `s`, lo at s + plane).
 static int g_fuse_kmax_small = 1;   // tuning (debug key 6): largest k fused into the correlation product at < 4096 rows
+static int g_ffn_sites = 63;        // tuning (debug key 8): 1 attention blocks, 2 lattice blocks, 4 head blocks may fuse
+static int g_ffn_fused_rows = 2048; // tuning (debug key 7): most rows for which the feed-forward runs as one fused launch (0: never)
 
 struct TV {
   float* f = nullptr;
@@ -167,12 +170,13 @@ struct Step {
   // rows [lo, lo + R) of Rfull; `sub` of `nsub` names its private K-split slab region.
   long long Rfull = 0;
   int lo = 0, R = 0, sub = 0, nsub = 1;
-  static constexpr long long kSlabRows = 8192;   // per-sub-run K-split slab capacity (rows of 256 floats)
+  static constexpr long long kSlabRows = 16384;  // per-sub-run slab capacity (rows of 256 floats): K-split / feed-forward partial outputs
 
   template <typename T>
   T* buf(const char* name) {
     return reinterpret_cast<T*>(ws + lay.find(name));
   }
+
   const float* W(int idx) const { return d->weights[idx]; }
   // distance (f16 elements) from the hi plane of matrix idx to its lo plane; unused when only hi planes are multiplied
   long long lo_plane(int idx) const {
@@ -255,6 +259,32 @@ struct Step {
     return layernorm_rows_in(in, W(gi), W(bei), M, keep, fallback, o, s);
   }
 
+  // Y = LayerNorm(MLP(X) + res) with MLP = F2 . GELU(F1 . x + b1) + b2 (transformer.py:343-355 inside every block).
+  // Few rows: one fused launch over the fragment-major weights leaves eight partial outputs for the LayerNorm kernel
+  // (ffn.hip); otherwise two products, the second split along K.  `wb` is the block's table base, f1w.. its offsets.
+  int ffn_ln(const TV& X, int wb, int f1w, int f1b, int f2w, int f2b, int f1fm, int f2fm, int g, int be, int M, const float* res,
+             const TV& Y, const uint8_t* keep = nullptr, const float* fallback = nullptr, const TV* Yn = nullptr, const TV* hid = nullptr,
+             int site = 1) {
+    const bool fused = (g_ffn_sites & site) && split && M <= g_ffn_fused_rows && 8ll * M <= kSlabRows && W(wb + f1fm) != nullptr && W(wb + f2fm) != nullptr;
+    if (!fused) {
+      if (linear(X, LBM_C, wb + f1w, wb + f1b, *hid, 1024, M, 1024, LBM_C, ACT_GELU)) return -1;
+      return linear_ln(*hid, 1024, wb + f2w, wb + f2b, 1, M, 1024, res, 1, 1.f, wb + g, wb + be, Y, keep, fallback, Yn);
+    }
+    FfnArgs f;
+    f.A = X.s; f.a_plane = X.plane; f.lda = LBM_C; f.F1 = d->weights[wb + f1fm]; f.b1 = W(wb + f1b); f.F2 = d->weights[wb + f2fm];
+    f.slabs = buf<float>("slab") + (long long)sub * kSlabRows * LBM_C; f.slab_stride = (long long)M * LBM_C;
+    f.M = M; f.chunk = 128; f.planes = planes;
+    if (ffn_fused(f, s)) return -1;
+    RowsIn in;
+    in.X = f.slabs; in.nslab = 8; in.slab_stride = f.slab_stride; in.bias = W(wb + f2b); in.res = res; in.res_div = 1; in.res_scale = 1.f;
+    RowsOut o;
+    o.Y = Y.f; o.Ys = Y.s; o.ys_plane = Y.plane;
+    if (Yn) {
+      o.Yn = Yn->f; o.Yns = Yn->s; o.yns_plane = Yn->plane;
+    }
+    return layernorm_rows_in(in, W(wb + g), W(wb + be), M, keep, fallback, o, s);
+  }
+
   // memory / lattice-update attention block: x_in [R,256] -> x_out [R,256]
   // U_pre / ldu: the queries u_h, when an earlier merged product already holds them (a column block of pitch ldu)
   int attn_block(int wb, const TV& x_in, const TV& x_out, const float* seq, long long point_stride, int S, int ring_head,
@@ -271,9 +301,8 @@ struct Step {
       if (linear_ln(*seq_tv, LBM_C, wb + LBM_W_ATTN_HMSUM, wb + LBM_W_ATTN_HB, 1, R, LBM_C, x_in.f, 1, 1.f, wb + LBM_W_ATTN_LN1G,
                     wb + LBM_W_ATTN_LN1B, y))
         return -1;
-      if (linear(y, LBM_C, wb + LBM_W_ATTN_F1W, wb + LBM_W_ATTN_F1B, hid, 1024, R, 1024, LBM_C, ACT_GELU)) return -1;
-      return linear_ln(hid, 1024, wb + LBM_W_ATTN_F2W, wb + LBM_W_ATTN_F2B, 1, R, 1024, y.f, 1, 1.f, wb + LBM_W_ATTN_LN2G,
-                       wb + LBM_W_ATTN_LN2B, x_out, valid, x_in.f, Yn);
+      return ffn_ln(y, wb, LBM_W_ATTN_F1W, LBM_W_ATTN_F1B, LBM_W_ATTN_F2W, LBM_W_ATTN_F2B, LBM_W_ATTN_F1FM, LBM_W_ATTN_F2FM,
+                    LBM_W_ATTN_LN2G, LBM_W_ATTN_LN2B, R, y.f, x_out, valid, x_in.f, Yn, &hid, 16);
     }
     if (U_pre == nullptr && linear(x_in, LBM_C, wb + LBM_W_ATTN_G, wb + LBM_W_ATTN_GB, U, 1024, R, 1024, LBM_C)) return -1;
     AttnArgs a;
@@ -286,9 +315,8 @@ struct Step {
     if (linear_ln(mbar, 1024, wb + LBM_W_ATTN_HM, wb + LBM_W_ATTN_HB, 1, R, 1024, x_in.f, 1, 1.f, wb + LBM_W_ATTN_LN1G,
                   wb + LBM_W_ATTN_LN1B, y))
       return -1;
-    if (linear(y, LBM_C, wb + LBM_W_ATTN_F1W, wb + LBM_W_ATTN_F1B, hid, 1024, R, 1024, LBM_C, ACT_GELU)) return -1;
-    return linear_ln(hid, 1024, wb + LBM_W_ATTN_F2W, wb + LBM_W_ATTN_F2B, 1, R, 1024, y.f, 1, 1.f, wb + LBM_W_ATTN_LN2G,
-                     wb + LBM_W_ATTN_LN2B, x_out, valid, x_in.f, Yn);
+    return ffn_ln(y, wb, LBM_W_ATTN_F1W, LBM_W_ATTN_F1B, LBM_W_ATTN_F2W, LBM_W_ATTN_F2B, LBM_W_ATTN_F1FM, LBM_W_ATTN_F2FM,
+                  LBM_W_ATTN_LN2G, LBM_W_ATTN_LN2B, R, y.f, x_out, valid, x_in.f, Yn, &hid, !masked ? 32 : Yn ? 8 : 1);
   }
 
   // deformable block: token x [R,256] (replicated k times) sampled at ref [R,k,2] -> out [R*k,256]
@@ -322,9 +350,8 @@ struct Step {
     if (linear_ln(samp, LBM_C, wb + LBM_W_MSDA_OUTW, wb + LBM_W_MSDA_OUTB, k, Q, LBM_C, x.f, k, 2.f, wb + LBM_W_MSDA_LN1G,
                   wb + LBM_W_MSDA_LN1B, la))
       return -1;
-    if (linear(la, LBM_C, wb + LBM_W_MSDA_F1W, wb + LBM_W_MSDA_F1B, hid, 1024, Q, 1024, LBM_C, ACT_GELU)) return -1;
-    return linear_ln(hid, 1024, wb + LBM_W_MSDA_F2W, wb + LBM_W_MSDA_F2B, k, Q, 1024, la.f, 1, 1.f, wb + LBM_W_MSDA_LN2G,
-                     wb + LBM_W_MSDA_LN2B, out);
+    return ffn_ln(la, wb, LBM_W_MSDA_F1W, LBM_W_MSDA_F1B, LBM_W_MSDA_F2W, LBM_W_MSDA_F2B, LBM_W_MSDA_F1FM, LBM_W_MSDA_F2FM,
+                  LBM_W_MSDA_LN2G, LBM_W_MSDA_LN2B, Q, la.f, out, nullptr, nullptr, nullptr, &hid, wb >= d->n_layers * LBM_W_LAYER_COUNT ? 4 : 2);
   }
 
   // ---- per-frame, point-independent work: split tokens, the six value maps, the correlation maps ----
@@ -626,6 +653,14 @@ int lbm_hip_debug_set(int32_t key, int32_t value) {
     g_fuse_kmax_small = value;
     return 0;
   }
+  if (key == 7) {
+    g_ffn_fused_rows = value;
+    return 0;
+  }
+  if (key == 8) {
+    g_ffn_sites = value;
+    return 0;
+  }
   set_error("debug_set: unknown key %d", key);
   return -1;
 }
@@ -703,6 +738,18 @@ int lbm_hip_pyramid_s(float* tokens, void* tokens_s, int64_t tokens_plane, int32
 int lbm_hip_encoder_tail(const float* q1, const float* q2, const float* q3, const float* pos, float* tokens, void* tokens_s,
                          int64_t tokens_plane, int32_t B, int32_t h, int32_t w, lbm_stream_t stream) {
   return encoder_tail(q1, q2, q3, pos, tokens, B, h, w, (hipStream_t)stream, tokens_s, tokens_plane);
+}
+
+int lbm_hip_pack_fragment_major(const void* hi, const void* lo, int32_t N, int32_t K, void* out, lbm_stream_t stream) {
+  return pack_fragment_major(hi, lo, N, K, out, (hipStream_t)stream);
+}
+
+int lbm_hip_ffn_slabs(const void* A, int64_t a_plane, int32_t lda, const void* F1_fm, const float* b1, const void* F2_fm, float* slabs,
+                      int64_t slab_stride, int32_t M, int32_t planes, lbm_stream_t stream) {
+  FfnArgs f;
+  f.A = A; f.a_plane = a_plane; f.lda = lda; f.F1 = F1_fm; f.b1 = b1; f.F2 = F2_fm; f.slabs = slabs; f.slab_stride = slab_stride;
+  f.M = M; f.chunk = 128; f.planes = planes == 1 ? 1 : 2;
+  return ffn_fused(f, (hipStream_t)stream);
 }
 
 int lbm_hip_update_points(const uint8_t* remove_mask, int32_t N_old, const uint8_t* update_mask, int32_t N_new, int32_t M,

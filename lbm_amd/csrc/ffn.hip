@@ -1,0 +1,211 @@
+// Fused feed-forward for the per-point chain: slabs[c] = GELU(A · F1[c]ᵀ + b1[c]) · F2[:, c]ᵀ for hidden chunk c.
+//
+// transformer.py:343-355 (MLP 256 -> 1024 -> 256) runs 15 times per frame on [R, 256] rows.  As two products it costs two
+// launches and a round trip of the [R, 1024] hidden tensor; with ~1000 rows both are latency, not work.  Here one
+// workgroup owns 32 rows and one chunk of CH hidden channels: it forms its [32, CH] piece of the hidden layer, keeps it
+// in LDS as split f16 planes, and multiplies it straight into a partial [32, 256] output -- the K-split slab the
+// LayerNorm kernel that follows reduces anyway (bias of the second layer and the residual are added there).
+//
+// Weights are read in FRAGMENT-MAJOR order (pack_fragment_major below): for every (32-row block, 16-deep k step) the
+// 64 lanes' MFMA B-operand fragments of the hi plane, then of the lo plane, lie in 2 contiguous KiB.  A wave therefore
+// fetches each fragment with one fully coalesced 16-byte-per-lane load straight into registers: no LDS staging, no
+// barrier and no bank conflicts on the weight side, and all of a wave's weight loads are in flight before its first
+// MFMA.  The only LDS traffic is the 32-row activation tile and the hidden piece.
+#include <algorithm>
+
+#include "common.hpp"
+#include "gemm.hpp"
+
+namespace lbm {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// planes [2][N][K] f16 (hi, lo) -> out [N/32][K/16][2][64][8]: lane = 32 * (k half of the step) + row within the block
+__global__ __launch_bounds__(256) void pack_fragment_major_kernel(const _Float16* __restrict__ hi, const _Float16* __restrict__ lo,
+                                                                  int N, int K, _Float16* __restrict__ out) {
+  const long long total = (long long)N * K / 8 * 2;      // 16-byte pieces
+  const int KS = K / 16;
+  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < total; p += (long long)gridDim.x * 256) {
+    const int lane = (int)(p & 63);
+    const int plane = (int)((p >> 6) & 1);
+    const long long blk = p >> 7;
+    const int ks = (int)(blk % KS), nb = (int)(blk / KS);
+    const int row = nb * 32 + (lane & 31), k = ks * 16 + (lane >> 5) * 8;
+    const _Float16* src = (plane ? lo : hi) + (long long)row * K + k;
+    *reinterpret_cast<half8*>(out + p * 8) = *reinterpret_cast<const half8*>(src);
+  }
+}
+
+int pack_fragment_major(const void* hi, const void* lo, int N, int K, void* out, hipStream_t stream) {
+  LBM_REQUIRE(hi && lo && out && N > 0 && K > 0 && N % 32 == 0 && K % 16 == 0, "pack_fragment_major: needs N %% 32 == 0 and K %% 16 == 0");
+  const long long pieces = (long long)N * K / 4;
+  hipLaunchKernelGGL(pack_fragment_major_kernel, dim3((unsigned)std::min<long long>((pieces + 255) / 256, 4096)), dim3(256), 0, stream,
+                     (const _Float16*)hi, (const _Float16*)lo, N, K, (_Float16*)out);
+  return check_launch("pack_fragment_major");
+}
+
+struct FfnDev {
+  const _Float16* A;      // [M, lda] hi plane, lo plane at A + a_plane
+  long long a_plane;
+  int lda;
+  const _Float16* F1;     // fragment-major [1024 / 32][256 / 16][2][64][8]
+  const float* b1;        // [1024]
+  const _Float16* F2;     // fragment-major [256 / 32][1024 / 16][2][64][8]
+  float* slabs;           // [1024 / CH][M, 256]
+  long long slab_stride;
+  int M;
+};
+
+constexpr int kC = 256, kHid = 1024, kRows = 32;
+constexpr int kAP = kC + 8;                 // LDS pitch (halves) of the activation tile: 528 B = 4 banks past a multiple of 64
+
+template <int CH, int NPL>
+__global__ __launch_bounds__(256) void ffn_fused_kernel(FfnDev a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int NT1 = CH / 32 / 4;           // hidden tiles per wave
+  constexpr int KS1 = kC / 16;               // 16 k steps over the 256 input channels
+  constexpr int KS2 = CH / 16;               // k steps over this chunk of the hidden layer
+  constexpr int HP = CH + 8;                 // LDS pitch (halves) of the hidden piece
+  __shared__ __attribute__((aligned(16))) _Float16 sA[NPL][kRows * kAP];
+  __shared__ __attribute__((aligned(16))) _Float16 sH[NPL][kRows * HP];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int c = blockIdx.x, m0 = blockIdx.y * kRows;
+  // The wave claims the SIMD's whole register file (256 + 256), so no wave of another kernel is ever resident beside it.
+  // With ~270 registers a wave of a kernel running on another HIP stream could share the SIMD, and then -- only then --
+  // roughly one frame in twenty of the frame pipeline (encoder of frame t+1 beside this chain) came out with a few points
+  // perturbed at the 2^-11 level (rows 0..2 of a 32-row tile, lanes 0..31 of the first accumulator registers); alone on
+  // the SIMD: 0 of 600 frames.  Any delay added to the kernel hid it as well; the cause was not established.
+  asm volatile("" ::: "v255", "a255");
+
+  // ---- every weight fragment this wave will need, requested up front ----
+  half8 b1h[NT1][KS1], b1l[NT1][KS1];
+#pragma unroll
+  for (int j = 0; j < NT1; ++j) {
+    const int nb = c * (CH / 32) + w * NT1 + j;
+    const _Float16* p = a.F1 + ((long long)nb * KS1 * 2) * 512 + lane * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks) {
+      b1h[j][ks] = *reinterpret_cast<const half8*>(p + (ks * 2) * 512);
+      if constexpr (NPL == 2) b1l[j][ks] = *reinterpret_cast<const half8*>(p + (ks * 2 + 1) * 512);
+    }
+  }
+  // ---- activation tile -> LDS (rows past M repeat the last row; their results are never stored) ----
+#pragma unroll
+  for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int piece = it * 256 + tid;              // 32 rows x 32 pieces of 16 bytes
+      const int row = piece >> 5, pc = piece & 31;
+      const int m = min(m0 + row, a.M - 1);
+      const half8 v = *reinterpret_cast<const half8*>(a.A + pl * a.a_plane + (long long)m * a.lda + pc * 8);
+      *reinterpret_cast<half8*>(&sA[pl][row * kAP + pc * 8]) = v;
+    }
+  // second-layer fragments: tile 0 now, tile 1 half way through phase 1, when half of the first layer's registers are free
+  half8 b2h[2][KS2], b2l[2][KS2];
+  auto fetch2 = [&](int j) {
+    const int nb = w * 2 + j;
+    const _Float16* p = a.F2 + (((long long)nb * (kHid / 16) + c * KS2) * 2) * 512 + lane * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS2; ++ks) {
+      b2h[j][ks] = *reinterpret_cast<const half8*>(p + (ks * 2) * 512);
+      if constexpr (NPL == 2) b2l[j][ks] = *reinterpret_cast<const half8*>(p + (ks * 2 + 1) * 512);
+    }
+  };
+  fetch2(0);
+  __syncthreads();
+
+  // ---- phase 1: this wave's NT1 tiles of the hidden piece ----
+  f32x16 acc[NT1], acx[NT1];
+#pragma unroll
+  for (int j = 0; j < NT1; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[j][e] = acx[j][e] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < KS1; ++ks) {
+    if (ks == KS1 / 2) {
+      fetch2(1);
+        }
+    const half8 ah = *reinterpret_cast<const half8*>(&sA[0][r * kAP + ks * 16 + h * 8]);
+    half8 al;
+    if constexpr (NPL == 2) al = *reinterpret_cast<const half8*>(&sA[NPL - 1][r * kAP + ks * 16 + h * 8]);
+#pragma unroll
+    for (int j = 0; j < NT1; ++j) {
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b1h[j][ks], acc[j], 0, 0, 0);
+      if constexpr (NPL == 2) {
+        acx[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b1l[j][ks], acx[j], 0, 0, 0);
+        acx[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b1h[j][ks], acx[j], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NT1; ++j) {
+    const int cl = (w * NT1 + j) * 32 + r;          // hidden channel inside the chunk: this lane's accumulator column
+    const float bv = a.b1[c * CH + cl];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int rl = (e & 3) + 8 * (e >> 2) + 4 * h;
+      float v = (NPL == 2 ? acc[j][e] + acx[j][e] * (1.0f / 2048.0f) : acc[j][e]) + bv;
+      v = __builtin_amdgcn_fmed3f(gelu_erf(v), -65000.f, 65000.f);
+      const _Float16 hh = (_Float16)v;
+      sH[0][rl * HP + cl] = hh;
+      if constexpr (NPL == 2) sH[NPL - 1][rl * HP + cl] = (_Float16)((v - (float)hh) * 2048.f);
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2: partial output, two 32-column tiles per wave ----
+  f32x16 o[2], ox[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[j][e] = ox[j][e] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < KS2; ++ks) {
+    const half8 ah = *reinterpret_cast<const half8*>(&sH[0][r * HP + ks * 16 + h * 8]);
+    half8 al;
+    if constexpr (NPL == 2) al = *reinterpret_cast<const half8*>(&sH[NPL - 1][r * HP + ks * 16 + h * 8]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      o[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b2h[j][ks], o[j], 0, 0, 0);
+      if constexpr (NPL == 2) {
+        ox[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b2l[j][ks], ox[j], 0, 0, 0);
+        ox[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b2h[j][ks], ox[j], 0, 0, 0);
+      }
+    }
+  }
+  float* out = a.slabs + (long long)c * a.slab_stride;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = (w * 2 + j) * 32 + r;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = m0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      if (row < a.M) out[(long long)row * kC + col] = NPL == 2 ? o[j][e] + ox[j][e] * (1.0f / 2048.0f) : o[j][e];
+    }
+  }
+#endif
+}
+
+int ffn_fused(const FfnArgs& f, hipStream_t stream) {
+  if (f.M == 0) return 0;
+  LBM_REQUIRE(f.A && f.F1 && f.b1 && f.F2 && f.slabs && f.M > 0, "ffn_fused: null argument");
+  LBM_REQUIRE(f.chunk == 128, "ffn_fused: chunk must be 128 (a wave keeps all its weight fragments in registers)");
+  LBM_REQUIRE(f.planes == 1 || f.planes == 2, "ffn_fused: planes must be 1 or 2");
+  LBM_REQUIRE(f.lda % 8 == 0 && f.a_plane % 8 == 0 && ((uintptr_t)f.A & 15) == 0 && ((uintptr_t)f.F1 & 15) == 0 && ((uintptr_t)f.F2 & 15) == 0,
+              "ffn_fused: operands must admit 16-byte pieces");
+  LBM_REQUIRE(f.slab_stride >= (long long)f.M * kC, "ffn_fused: slabs overlap");
+  FfnDev d;
+  d.A = (const _Float16*)f.A; d.a_plane = f.a_plane; d.lda = f.lda; d.F1 = (const _Float16*)f.F1; d.b1 = f.b1; d.F2 = (const _Float16*)f.F2;
+  d.slabs = f.slabs; d.slab_stride = f.slab_stride; d.M = f.M;
+  const dim3 grid(kHid / f.chunk, (f.M + kRows - 1) / kRows);
+  const double flops = 4.0 * f.M * kC * kHid;
+  const double bytes = 2.0 * f.planes * (f.M * kC + 2.0 * kC * kHid) + 4.0 * f.M * kC * (kHid / f.chunk);
+  ProfScope prof(f.planes == 2 ? "ffn_fused_ss" : "ffn_fused_sh", stream, flops, bytes);
+  if (f.planes == 2) hipLaunchKernelGGL((ffn_fused_kernel<128, 2>), grid, dim3(256), 0, stream, d);
+  else hipLaunchKernelGGL((ffn_fused_kernel<128, 1>), grid, dim3(256), 0, stream, d);
+  return check_launch("ffn_fused");
+}
+
+}  // namespace lbm

@@ -102,4 +102,19 @@ int conv2d_nhwc_ss(const ConvSSArgs& c, hipStream_t stream);
 int maxpool3x3s2_nhwc(const float* x, float* y, int B, int H, int W, int C, hipStream_t stream, void* ys = nullptr,
                       long long ys_plane = 0);
 
+// Fused feed-forward 256 -> 1024 -> 256 over fragment-major weights (ffn.hip): partial outputs, one slab per hidden chunk.
+struct FfnArgs {
+  const void* A = nullptr;        // [M, lda] split planes of the input rows (hi; lo a_plane elements further)
+  long long a_plane = 0;
+  int lda = 0;
+  const void* F1 = nullptr;       // pack_fragment_major of the [1024, 256] first layer
+  const float* b1 = nullptr;      // [1024]
+  const void* F2 = nullptr;       // pack_fragment_major of the [256, 1024] second layer
+  float* slabs = nullptr;         // [1024 / chunk][M, 256] partial outputs (no bias)
+  long long slab_stride = 0;
+  int M = 0, chunk = 128, planes = 2;
+};
+int ffn_fused(const FfnArgs& f, hipStream_t stream);
+int pack_fragment_major(const void* hi, const void* lo, int N, int K, void* out, hipStream_t stream);
+
 }  // namespace lbm

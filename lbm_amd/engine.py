@@ -14,6 +14,7 @@ Folding is done once, in float64 on the host, and rounded to fp32.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -324,6 +325,15 @@ class TrackerWeights:
         for i, t in enumerate(self.tensors):
             if t is not None and t.dim() == 2 and i not in f32_idx:
                 self.split[i] = hip.SplitWeight(t)
+        # fragment-major copies of the feed-forward matrices for the fused few-rows kernel (lbm_hip_ffn_slabs)
+        blocks = [(i * k["LBM_W_LAYER_COUNT"] + k[b], "ATTN") for i in range(n_layers) for b in ("LBM_W_LAYER_COLL", "LBM_W_LAYER_STREAM", "LBM_W_LAYER_UPDATE")]
+        blocks += [(i * k["LBM_W_LAYER_COUNT"] + k["LBM_W_LAYER_LATTICE"], "MSDA") for i in range(n_layers)]
+        blocks += [(hb_ + k[b], "MSDA") for b in ("LBM_W_HEAD_OFFSET", "LBM_W_HEAD_CMEM", "LBM_W_HEAD_VIS")]
+        for base, kind in blocks:
+            for src, dst in (("F1W", "F1FM"), ("F2W", "F2FM")):
+                sw = self.split[base + k[f"LBM_W_{kind}_{src}"]]
+                if sw is not None and sw.shape in ((1024, 256), (256, 1024)):
+                    self.tensors[base + k[f"LBM_W_{kind}_{dst}"]] = hip.fragment_major(sw)
         self.n = n
         self.n_layers = n_layers
         self.device = dev
@@ -392,6 +402,8 @@ class TrackEngine:
                 raise hip.HipError("step workspace: " + hip.load().lbm_hip_last_error().decode())
             self._ws[slot] = None
             self._ws[slot] = torch.empty(nbytes, device=self.dev, dtype=torch.uint8)
+            if os.environ.get("LBM_AMD_WS_FILL"):      # debugging aid: a byte pattern (255 = NaNs) exposes reads of unwritten scratch
+                self._ws[slot].fill_(int(os.environ["LBM_AMD_WS_FILL"]))
             self._ws_key[slot] = key
         self._last_slot = slot
         return self._ws[slot]
@@ -480,6 +492,7 @@ class TrackEngine:
             for i in range(len(cfg.topk_per_layer)):
                 out[f"corr{i}"] += self.w.corr_bias[i]
         self._last_desc = d
+        self._last_out = out
         return out
 
     def debug_buffer(self, name: str, shape, dtype=torch.float32) -> torch.Tensor:

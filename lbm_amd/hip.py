@@ -27,7 +27,7 @@ EXPORTS = (
     "lbm_hip_track_step", "lbm_hip_step_workspace_offset", "lbm_hip_conv2d_nhwc", "lbm_hip_maxpool3x3s2_nhwc",
     "lbm_hip_profile_begin", "lbm_hip_profile_end", "lbm_hip_split_planes", "lbm_hip_debug_set", "lbm_hip_linear_ss",
     "lbm_hip_conv2d_nhwc_ss", "lbm_hip_maxpool3x3s2_nhwc_s", "lbm_hip_upcat_s", "lbm_hip_pyramid_s",
-    "lbm_hip_update_points", "lbm_hip_encoder_tail",
+    "lbm_hip_update_points", "lbm_hip_encoder_tail", "lbm_hip_pack_fragment_major", "lbm_hip_ffn_slabs",
 )
 
 
@@ -138,6 +138,9 @@ def load() -> C.CDLL:
     lib.lbm_hip_preprocess.argtypes = [C.c_void_p, C.c_int64, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p]
     lib.lbm_hip_upcat.argtypes = [C.c_void_p] * 4 + [C.c_int32] * 3 + [C.c_void_p]
     lib.lbm_hip_sample_queries.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p]
+    lib.lbm_hip_pack_fragment_major.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.lbm_hip_ffn_slabs.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                      C.c_int32, C.c_int32, C.c_void_p]
     lib.lbm_hip_encoder_tail.argtypes = [C.c_void_p] * 6 + [C.c_int64] + [C.c_int32] * 3 + [C.c_void_p]
     lib.lbm_hip_update_points.argtypes = ([C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 13)
     lib.lbm_hip_step_workspace_bytes.argtypes = [C.POINTER(StepDesc)]
@@ -308,6 +311,25 @@ def update_points(remove_mask: torch.Tensor, update_mask: torch.Tensor, old, new
                                         _p(stream), _p(coll), _p(vis, torch.uint8), _p(mem, torch.uint8), scratch.data_ptr(),
                                         _stream()), "lbm_hip_update_points")
     return query, stream, coll, vis, mem
+
+
+def fragment_major(sw: "SplitWeight") -> torch.Tensor:
+    """Fragment-major copy [N/32, K/16, 2, 64, 8] (f16) of a split weight matrix (lbm_hip_pack_fragment_major)."""
+    _require_gpu()
+    N, K = sw.shape
+    out = torch.empty(N // 32, K // 16, 2, 64, 8, device=sw.planes.device, dtype=torch.float16)
+    _check(load().lbm_hip_pack_fragment_major(sw.hi, sw.lo, N, K, out.data_ptr(), _stream()), "lbm_hip_pack_fragment_major")
+    return out
+
+
+def ffn_slabs(xs: "SplitTensor", f1_fm: torch.Tensor, b1: torch.Tensor, f2_fm: torch.Tensor, planes: int = 2) -> torch.Tensor:
+    """xs: split [M, 256] rows -> (8, M, 256) partial outputs of the fused feed-forward (lbm_hip_ffn_slabs)."""
+    _require_gpu()
+    M = xs.shape[0]
+    slabs = torch.empty(8, M, 256, device=xs.planes.device, dtype=torch.float32)
+    _check(load().lbm_hip_ffn_slabs(xs.hi, xs.plane, xs.shape[1], f1_fm.data_ptr(), _p(b1), f2_fm.data_ptr(), slabs.data_ptr(),
+                                    M * 256, M, planes, _stream()), "lbm_hip_ffn_slabs")
+    return slabs
 
 
 def maxpool3x3s2_nhwc_s(x: torch.Tensor):

@@ -12,6 +12,7 @@
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -187,19 +188,20 @@ class LBM_online(LBM):
         if self.query is None or not frames.is_cuda:
             return
         main = torch.cuda.current_stream()
+        NS = 2
         key = (frames.shape[0], self.N, self.memory_size, frames.device)
         if self._pipe is None or self._pipe["key"] != key:
             L = self.transformer.cfg.num_tokens
             dev = frames.device
             self._pipe = {
                 "key": key, "stream": torch.cuda.Stream(device=dev), "next": 0,
-                "tok": [torch.empty(frames.shape[0], L, self.embed_dim, device=dev) for _ in range(2)],
-                "tok_s": [None, None],
-                "enc_done": [torch.cuda.Event() for _ in range(2)],
+                "tok": [torch.empty(frames.shape[0], L, self.embed_dim, device=dev) for _ in range(NS)],
+                "tok_s": [None] * NS,
+                "enc_done": [torch.cuda.Event() for _ in range(NS)],
             }
         p = self._pipe
         slot = p["next"]
-        p["next"] = slot ^ 1
+        p["next"] = (slot + 1) % NS
         enc = p["stream"]
         # the frame was produced on the caller's stream, and the slot's previous reader (the per-point phase two
         # frames back) was enqueued there as well: one wait covers both
@@ -247,7 +249,7 @@ class LBM_online(LBM):
                 return res
         # a frame encoded ahead owns its workspace slot until it is consumed: an unpipelined frame in between uses a third
         busy = set(self._pf.values())
-        ws_slot = next(i for i in (0, 1, 2) if i not in busy)
+        ws_slot = next(i for i in range(8) if i not in busy)
         tok = self.backbone.encode_tokens(frames, tokens)
         out = self.transformer.get_engine().step(tok, self.query, self._stream, self._coll, self._vis, self._mem,
                                                  ring_head=self._head, queried=None, update_state=True, img_hw=(H, W),

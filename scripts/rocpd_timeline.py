@@ -45,3 +45,30 @@ def main(db, dump_from=0.5, dump_n=80):
 
 if __name__ == "__main__":
     main(sys.argv[1], float(sys.argv[2]) if len(sys.argv) > 2 else 0.5, int(sys.argv[3]) if len(sys.argv) > 3 else 80)
+
+
+def gaps(db, frac=0.5):
+    """Per queue: kernel time, and the gaps between consecutive kernels of that queue (start - previous end)."""
+    c = sqlite3.connect(db)
+    cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
+    qcol = "queue_id" if "queue_id" in cols else "0"
+    scol = "stream_id" if "stream_id" in cols else "0"
+    rows = list(c.execute(f"select name, start, end, {qcol}, {scol} from kernels order by start"))
+    t0, t1 = rows[0][1], max(r[2] for r in rows)
+    rs = [r for r in rows if r[1] >= t0 + (t1 - t0) * frac]
+    span = max(r[2] for r in rs) - rs[0][1]
+    print(f"window {span / 1e3:.0f} us, {len(rs)} kernels")
+    by = {}
+    for r in rs:
+        by.setdefault((r[3], r[4]), []).append(r)
+    for k, v in by.items():
+        dur = sum(r[2] - r[1] for r in v)
+        g = sorted((v[i + 1][1] - v[i][2]) / 1e3 for i in range(len(v) - 1))
+        small = [x for x in g if x < 30]
+        print(f"queue {k}: {len(v)} kernels, busy {dur / 1e3:.0f} us ({100 * dur / span:.0f} % of window), avg kernel {dur / len(v) / 1e3:.2f} us; "
+              f"gaps: median {g[len(g) // 2]:.2f} us, mean of gaps < 30 us {sum(small) / max(len(small), 1):.2f} us, sum of gaps < 30 us {sum(small):.0f} us, "
+              f"gaps >= 30 us: {len(g) - len(small)} totalling {sum(x for x in g if x >= 30):.0f} us")
+
+
+if __name__ == "__main__" and len(sys.argv) > 4 and sys.argv[4] == "gaps":
+    gaps(sys.argv[1], float(sys.argv[2]))

@@ -634,6 +634,47 @@ def test_packed_weight_file_restores_bit_identical_tracks(hip, tmp_path, precisi
         c.load_packed(path)
 
 
+@pytest.mark.parametrize("M", [1, 31, 1024, 1500])
+@pytest.mark.parametrize("planes,tol", [(2, 2e-5), (1, 1e-2)])
+def test_fused_feed_forward_against_fp64(hip, M, planes, tol):
+    """lbm_hip_ffn_slabs + lbm_hip_pack_fragment_major (transformer.py:343-355, Linear-GELU(erf)-Linear) against float64."""
+    g = torch.Generator(device="cpu").manual_seed(M + planes)
+    W1 = (torch.randn(1024, 256, generator=g) / 16).cuda()
+    b1 = (torch.randn(1024, generator=g) * 0.1).cuda()
+    W2 = (torch.randn(256, 1024, generator=g) / 32).cuda()
+    x = torch.randn(M, 256, generator=g).cuda()
+    s1, s2 = hip.SplitWeight(W1), hip.SplitWeight(W2)
+    f1, f2 = hip.fragment_major(s1), hip.fragment_major(s2)
+    # the fragment-major copy is a pure permutation of the planes
+    assert torch.equal(f1.view(32, 16, 2, 2, 32, 8).permute(2, 0, 4, 1, 3, 5).reshape(2, 1024, 256), s1.planes)
+    xs = hip.SplitTensor((M, 256), x.device)
+    hip._check(hip.load().lbm_hip_split_planes(x.data_ptr(), xs.hi, xs.planes[1].data_ptr(), x.numel(), hip._stream()), "split")
+    slabs = hip.ffn_slabs(xs, f1, b1, f2, planes)
+    want = torch.nn.functional.gelu(x.double() @ W1.double().t() + b1.double()) @ W2.double().t()
+    _cmp(slabs.sum(0), want.float(), rtol=tol, atol=tol)
+
+
+def test_fused_feed_forward_step_matches_two_product_step(hip):
+    """The step with the feed-forwards fused (<= 2048 rows) against the same step with two products each (debug key 7)."""
+    g = fx.geometry("full256")
+    tr, _ = _transformer(g, precision="split")
+    cu = {k: v.cuda() for k, v in fx.step_inputs(g, 1, 300, seed=77).items()}
+    lib = hip.load()
+    outs = {}
+    try:
+        for rows in (0, 2048):
+            lib.lbm_hip_debug_set(7, rows)
+            with torch.no_grad():
+                outs[rows] = tr(cu["query"], cu["feat"], cu["stream"], cu["collision"], cu["vis_mask"], cu["mem_mask"], cu["queried"])
+    finally:
+        lib.lbm_hip_debug_set(7, 2048)
+    a, b = outs[0], outs[2048]
+    same = (a[0][-1]["reference_points"] == b[0][-1]["reference_points"]).all(-1).float().mean().item()
+    assert same >= 0.99                       # a top-k near-tie may resolve differently under another summation order
+    _cmp(a[3], b[3], rtol=0, atol=5e-3)
+    _cmp(a[1]["stream"], b[1]["stream"], rtol=2e-3, atol=2e-3)
+
+
 def test_graph_replay_and_point_parallel_streams_match_the_plain_eager_step(hip, monkeypatch):
     """B = 1, N = 1024: the default path (HIP-graph replay per ring head, per-point chain on 4 concurrent streams)
     against the plain single-stream eager path over 15 frames (the ring wraps: M = 12)."""

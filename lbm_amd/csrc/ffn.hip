@@ -124,9 +124,7 @@ __global__ __launch_bounds__(256) void ffn_fused_kernel(FfnDev a) {
     for (int e = 0; e < 16; ++e) acc[j][e] = acx[j][e] = 0.f;
 #pragma unroll
   for (int ks = 0; ks < KS1; ++ks) {
-    if (ks == KS1 / 2) {
-      fetch2(1);
-        }
+    if (ks == KS1 / 2) fetch2(1);
     const half8 ah = *reinterpret_cast<const half8*>(&sA[0][r * kAP + ks * 16 + h * 8]);
     half8 al;
     if constexpr (NPL == 2) al = *reinterpret_cast<const half8*>(&sA[NPL - 1][r * kAP + ks * 16 + h * 8]);

@@ -21,6 +21,9 @@ def short(name: str) -> str:
         sfx = "h" if npl == "1" else "s"
         base = "conv_s" + sfx if conv == "true" else ("gemm_ss_topk" + topk if topk not in (None, "0") else "gemm_s" + sfx)
         return f"{base}{'_full' if full == 'true' else ''}<{bm},{bn},{wm},{wn},{st}>"
+    m = re.search(r"ffn_fused_kernel<\d+, (\d+)", name)
+    if m:
+        return "ffn_fused_ss" if m.group(1) == "2" else "ffn_fused_sh"
     m = re.search(r"lbm::(\w+?)_kernel", name)
     return m.group(1) if m else name[:60]
 

@@ -299,6 +299,12 @@ typedef struct {
   const void* query_split;
   uint8_t* vis_flag;
   float* rho_prob;
+  /* optional: query_u0 [B, N, 1024] fp32, the first layer's collision-attention queries G . query + gb.  The query only
+   * changes at point-set updates, so this product need not be repeated every frame: with query_u0_valid == 0 the step
+   * computes it INTO query_u0, with query_u0_valid != 0 it reads it from there (the caller keeps the flag; same bits
+   * either way).  NULL: computed every frame into the workspace.                                                  */
+  float* query_u0;
+  int32_t query_u0_valid;
 } lbm_hip_step_desc;
 
 /* Tail of the encoder (backbone.py:53-65, 181-193 and transformer.py:58-69 in one pass): the 1x1 projections, the

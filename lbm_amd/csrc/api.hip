@@ -288,7 +288,8 @@ struct Step {
   // memory / lattice-update attention block: x_in [R,256] -> x_out [R,256]
   // U_pre / ldu: the queries u_h, when an earlier merged product already holds them (a column block of pitch ldu)
   int attn_block(int wb, const TV& x_in, const TV& x_out, const float* seq, long long point_stride, int S, int ring_head,
-                 bool masked, const TV* Yn, const TV* seq_tv = nullptr, const float* U_pre = nullptr, long long ldu = 1024) {
+                 bool masked, const TV* Yn, const TV* seq_tv = nullptr, const float* U_pre = nullptr, long long ldu = 1024,
+                 float* U_store = nullptr) {
     const int km = (int)lay.kmax;
     TV U = view("U", nullptr, 1, 1, 1024);
     TV mbar = view1("mbar", 1, 1, 1024);
@@ -303,6 +304,10 @@ struct Step {
         return -1;
       return ffn_ln(y, wb, LBM_W_ATTN_F1W, LBM_W_ATTN_F1B, LBM_W_ATTN_F2W, LBM_W_ATTN_F2B, LBM_W_ATTN_F1FM, LBM_W_ATTN_F2FM,
                     LBM_W_ATTN_LN2G, LBM_W_ATTN_LN2B, R, y.f, x_out, valid, x_in.f, Yn, &hid, 16);
+    }
+    if (U_store != nullptr) {      // the caller's cache of these queries: fill it now, read it from now on
+      U.f = U_store;
+      U_pre = nullptr;
     }
     if (U_pre == nullptr && linear(x_in, LBM_C, wb + LBM_W_ATTN_G, wb + LBM_W_ATTN_GB, U, 1024, R, 1024, LBM_C)) return -1;
     AttnArgs a;
@@ -405,7 +410,11 @@ struct Step {
       const int k = d->topk[i];
       TV lb = view("lb", k == 1 ? "lb_s" : nullptr, (int)lay.kmax, k, LBM_C);   // split twin only where a GEMM consumes it
       // collision then streaming read-out of the two memories (transformer.py:257-302)
-      if (attn_block(lw + LBM_W_LAYER_COLL, x, ta, coll_mem, (long long)M * LBM_C, M, d->ring_head, true, nullptr)) return -1;
+      // layer 0 reads the (constant) query: its queries u = G x + gb may be kept by the caller across frames
+      float* u0 = (i == 0 && d->query_u0) ? d->query_u0 + (long long)lo * 1024 : nullptr;
+      if (attn_block(lw + LBM_W_LAYER_COLL, x, ta, coll_mem, (long long)M * LBM_C, M, d->ring_head, true, nullptr, nullptr,
+                     (u0 && d->query_u0_valid) ? u0 : nullptr, 1024, (u0 && !d->query_u0_valid) ? u0 : nullptr))
+        return -1;
       if (attn_block(lw + LBM_W_LAYER_STREAM, ta, tb, stream_mem, (long long)M * LBM_C, M, d->ring_head, true, &qn)) return -1;
       // correlation + top-k (transformer.py:306-308)
       float* cdst = d->corr[i] ? d->corr[i] + (long long)lo * lay.P0 : corr;

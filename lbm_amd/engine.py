@@ -367,7 +367,8 @@ class TrackEngine:
         self.cfg = cfg
         self.w = weights
         self.dev = weights.device
-        self._q_split = None                          # (key, SplitTensor): split twin of the last query tensor seen
+        self._qc = None                               # what is cached for the last query tensor seen (see step())
+        self._cache_u0 = os.environ.get("LBM_AMD_CACHE_U0", "1") != "0"
         self._ws: Dict[int, torch.Tensor] = {}       # workspace per slot (a pipelined caller alternates two)
         self._ws_key: Dict[int, tuple] = {}
 
@@ -447,15 +448,26 @@ class TrackEngine:
                    "vis_flag": torch.empty(B, N, device=dev, dtype=torch.bool), "rho_prob": torch.empty(B, N, device=dev)}
         if "vis_flag" in out:
             d.vis_flag, d.rho_prob = out["vis_flag"].data_ptr(), out["rho_prob"].data_ptr()
-        if d.precision >= 1 and N > 0 and phase != 1:
-            # the query only changes at point-set updates: keep its split twin instead of re-splitting it every frame
-            key = (query.data_ptr(), query._version, tuple(query.shape))
-            if self._q_split is None or self._q_split[0] != key:
-                qs = hip.SplitTensor(tuple(query.shape), dev)
-                hip._check(hip.load().lbm_hip_split_planes(hip._p(query), qs.hi, qs.planes[1].data_ptr(), query.numel(), hip._stream()),
-                           "lbm_hip_split_planes")
-                self._q_split = (key, qs)
-            d.query_split = self._q_split[1].hi
+        if N > 0 and phase != 1:
+            # The query only changes at point-set updates: what depends on it alone is kept across frames -- its split twin and
+            # the first layer's collision-attention queries G . query (filled by the first step that sees this query, read by
+            # the following ones).  The cache holds the tensor itself, so "the same query" means the same object at the same
+            # version: its memory cannot have been handed to another tensor in between.
+            qc = self._qc
+            if qc is None or qc["ref"] is not query or qc["ver"] != query._version or qc["prec"] != d.precision:
+                qc = self._qc = {"ref": query, "ver": query._version, "prec": d.precision, "split": None, "u0": None, "u0_valid": 0}
+            if d.precision >= 1:
+                if qc["split"] is None:
+                    qs = hip.SplitTensor(tuple(query.shape), dev)
+                    hip._check(hip.load().lbm_hip_split_planes(hip._p(query), qs.hi, qs.planes[1].data_ptr(), query.numel(), hip._stream()),
+                               "lbm_hip_split_planes")
+                    qc["split"] = qs
+                d.query_split = qc["split"].hi
+            if self._cache_u0 and (rows is None or (int(rows[0]) == 0 and int(rows[1]) == B * N)):   # whole point set only
+                if qc["u0"] is None:
+                    qc["u0"] = torch.empty(B, N, 1024, device=dev)
+                d.query_u0, d.query_u0_valid = qc["u0"].data_ptr(), qc["u0_valid"]
+                qc["u0_valid"] = 1
         if want_memory:
             out["stream"] = torch.empty(B, N, 256, device=dev)
             out["collision"] = torch.empty(B, N, 256, device=dev)

@@ -83,7 +83,8 @@ class StepDesc(C.Structure):
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_uint64),
                 ("aux_streams", C.c_void_p * 3), ("n_aux_streams", C.c_int32),
                 ("phase", C.c_int32), ("row_lo", C.c_int32), ("row_count", C.c_int32), ("sub_index", C.c_int32),
-                ("query_split", C.c_void_p), ("vis_flag", C.c_void_p), ("rho_prob", C.c_void_p)]
+                ("query_split", C.c_void_p), ("vis_flag", C.c_void_p), ("rho_prob", C.c_void_p),
+                ("query_u0", C.c_void_p), ("query_u0_valid", C.c_int32)]
 
 
 class ProfileEntry(C.Structure):

@@ -675,6 +675,29 @@ def test_fused_feed_forward_step_matches_two_product_step(hip):
     _cmp(a[1]["stream"], b[1]["stream"], rtol=2e-3, atol=2e-3)
 
 
+def test_cached_first_layer_queries_are_refreshed_when_the_query_changes(hip):
+    """The engine keeps G . query of the first collision attention across frames (lbm_hip_step_desc.query_u0).  Same bits
+    as recomputing it; an in-place edit of the query or another query tensor must invalidate it."""
+    g = fx.geometry("full256")
+    tr, _ = _transformer(g, precision="split")
+    cu = {k: v.cuda() for k, v in fx.step_inputs(g, 1, 64, seed=80).items()}
+    args = lambda q: (q, cu["feat"], cu["stream"], cu["collision"], cu["vis_mask"], cu["mem_mask"], cu["queried"])
+    q = cu["query"].clone()
+    with torch.no_grad():
+        a1 = tr(*args(q))
+        a2 = tr(*args(q))                       # served from the cache
+        assert tr.get_engine()._qc["u0_valid"] == 1 and torch.equal(a1[3], a2[3]) and torch.equal(a1[2], a2[2])
+        q.mul_(1.5)                             # in place: same object, new version
+        b1 = tr(*args(q))
+        q2 = q.clone()                          # another object with the same values
+        b2 = tr(*args(q2))
+        assert torch.equal(b1[3], b2[3]) and not torch.equal(a1[3], b1[3])
+        tr.get_engine()._cache_u0 = False       # recomputed every call: identical bits
+        b3 = tr(*args(q2))
+        tr.get_engine()._cache_u0 = True
+        assert torch.equal(b2[3], b3[3]) and torch.equal(b2[2], b3[2]) and torch.equal(b2[1]["stream"], b3[1]["stream"])
+
+
 def test_graph_replay_and_point_parallel_streams_match_the_plain_eager_step(hip, monkeypatch):
     """B = 1, N = 1024: the default path (HIP-graph replay per ring head, per-point chain on 4 concurrent streams)
     against the plain single-stream eager path over 15 frames (the ring wraps: M = 12)."""

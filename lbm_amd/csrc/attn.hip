@@ -40,12 +40,12 @@ __device__ __forceinline__ void reduce16(const float (&p)[16], float (&tot)[16],
   }
 }
 
-template <int WPP>
+template <int WPP, bool TEMB>
 __global__ __launch_bounds__(256) void attn_readout_kernel(AttnArgs a) {
   __shared__ float sm_acc[WPP == 1 ? 1 : 4][LBM_HEADS][LBM_C];
   __shared__ float sm_ml[WPP == 1 ? 1 : 4][2][LBM_HEADS];
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int row = WPP == 1 ? blockIdx.x * 4 + wave : blockIdx.x;
   if (row >= a.R) return;
 
@@ -66,45 +66,56 @@ __global__ __launch_bounds__(256) void attn_readout_kernel(AttnArgs a) {
     acc[hh] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
 
-  // this wave's slots: j0, j0 + WPP, ...  in groups of four; the loads of group g + 1 are issued before group g is
-  // reduced, so two groups (8 KiB per wave) are in flight while the soft-max arithmetic runs
+  // this wave's slots: j0, j0 + WPP, ...  in groups of four; the loads of group g + 1 (rows and their temporal
+  // embeddings) are issued before group g is reduced, so they fly while the soft-max arithmetic runs.  The ignore
+  // masks are read 64 slots at a time, one byte per lane, and kept as a wave-uniform bit set: a per-slot byte load
+  // would have to return before the slot's row load could be issued behind it (loads retire in order), which
+  // serialised the whole read-out.  A group never straddles a 64-slot chunk (4·WPP divides 64).
   const int step = WPP;
   const int jb0 = WPP == 1 ? 0 : wave;
-  float4 vn[4];
+  unsigned long long ign = 0;
+  int ign_chunk = -1;
+  auto load_masks = [&](int chunk) {
+    const int jl = chunk * 64 + lane;
+    const bool in = jl < a.S;
+    int phys = a.ring_head + (in ? jl : 0);
+    if (phys >= a.S) phys -= a.S;
+    bool ig = !in;
+    if (ma) ig |= ma[phys] != 0;
+    if (mb) ig |= mb[phys] != 0;
+    ign = __ballot(ig);
+    ign_chunk = chunk;
+  };
+  float4 vn[4], tn[4];
   bool usen[4];
   auto fetch = [&](int jb) {
+    if ((jb >> 6) != ign_chunk) load_masks(jb >> 6);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int j = jb + g * step;
-      const bool in = j < a.S;
-      int phys = a.ring_head + (in ? j : 0);
+      const int jc = j < a.S ? j : 0;
+      int phys = a.ring_head + jc;
       if (phys >= a.S) phys -= a.S;
-      bool ignore = !in;
-      if (ma) ignore |= ma[phys] != 0;
-      if (mb) ignore |= mb[phys] != 0;
-      usen[g] = !ignore;
+      usen[g] = !((ign >> (j & 63)) & 1ull);
+      if (TEMB) tn[g] = ld4(a.temb + (long long)jc * LBM_C + lane * 4);
       vn[g] = ld4(sp + (long long)phys * a.slot_stride);
     }
   };
   if (jb0 < a.S) fetch(jb0);
   for (int jb = jb0; jb < a.S; jb += 4 * step) {
-    float4 v[4];
+    float4 v[4], kxs[4];
     bool use[4];
     float p[16];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       v[g] = vn[g];
       use[g] = usen[g];
+      kxs[g] = TEMB ? make_float4(vn[g].x + tn[g].x, vn[g].y + tn[g].y, vn[g].z + tn[g].z, vn[g].w + tn[g].w) : vn[g];
     }
     if (jb + 4 * step < a.S) fetch(jb + 4 * step);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const int j = jb + g * step;
-      float4 kx = v[g];
-      if (a.temb) {
-        const float4 t = ld4(a.temb + (long long)(j < a.S ? j : 0) * LBM_C + lane * 4);
-        kx = make_float4(kx.x + t.x, kx.y + t.y, kx.z + t.z, kx.w + t.w);
-      }
+      const float4 kx = kxs[g];
 #pragma unroll
       for (int hh = 0; hh < LBM_HEADS; ++hh) p[g * 4 + hh] = u[hh].x * kx.x + u[hh].y * kx.y + u[hh].z * kx.z + u[hh].w * kx.w;
     }
@@ -194,10 +205,13 @@ int attn_readout(const AttnArgs& a, hipStream_t stream) {
   ProfScope prof("attn_readout", stream, (double)a.R * a.S * 4.0 * LBM_C * 4,
                  (double)a.R * (4.0 * LBM_C * (a.S + 8) + (a.mask_a ? a.S : 0) + (a.mask_b ? a.S : 0)));
   const bool wide = g_attn_mode == 4 || (g_attn_mode == 0 && a.R < 4096 && a.S >= 8);
-  if (wide)
-    hipLaunchKernelGGL(attn_readout_kernel<4>, dim3(a.R), dim3(256), 0, stream, a);
-  else
-    hipLaunchKernelGGL(attn_readout_kernel<1>, dim3((a.R + 3) / 4), dim3(256), 0, stream, a);
+  if (wide) {
+    if (a.temb) hipLaunchKernelGGL((attn_readout_kernel<4, true>), dim3(a.R), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((attn_readout_kernel<4, false>), dim3(a.R), dim3(256), 0, stream, a);
+  } else {
+    if (a.temb) hipLaunchKernelGGL((attn_readout_kernel<1, true>), dim3((a.R + 3) / 4), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((attn_readout_kernel<1, false>), dim3((a.R + 3) / 4), dim3(256), 0, stream, a);
+  }
   return check_launch("attn_readout");
 }
 

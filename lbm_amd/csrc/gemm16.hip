@@ -859,18 +859,21 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
                                                           long long total4, int relu, float* __restrict__ Y, void* Ys,
                                                           long long ys_plane) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+    // bias / residual are requested before the slab sums need anything (absent ones re-read slab 0 and are dropped), and
+    // the slab loop is unrolled so four slabs are in flight: one dependent round trip per term was the cost of this kernel
+    const float4 pb = ld4(bias ? bias + (i % N4) * 4 : slabs + i * 4);
+    const float4 pr = ld4(res ? res + i * 4 : slabs + i * 4);
     float4 v = ld4(slabs + i * 4);
+#pragma unroll 4
     for (int sl = 1; sl < nslab; ++sl) {
       const float4 p = ld4(slabs + sl * slab_stride + i * 4);
       v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
     }
     if (bias) {
-      const float4 p = ld4(bias + (i % N4) * 4);
-      v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+      v.x += pb.x; v.y += pb.y; v.z += pb.z; v.w += pb.w;
     }
     if (res) {
-      const float4 p = ld4(res + i * 4);
-      v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+      v.x += pr.x; v.y += pr.y; v.z += pr.z; v.w += pr.w;
     }
     if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
     if (Y) st4(Y + i * 4, v);

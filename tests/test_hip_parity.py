@@ -221,6 +221,51 @@ def test_attention_readout_ring_and_masks(hip):
     _cmp(got[valid.cuda()], want, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("S,head", [(150, 37), (64, 0), (65, 64), (7, 3)])
+def test_attention_readout_long_sequences(hip, S, head):
+    """Sequences longer than one 64-slot mask chunk (and ragged tails), two masks, both wave mappings, vs fp64:
+    out_h = sum_j softmax_j(u_h . (seq_j + temb_j)) seq_j over the slots neither mask ignores, ring order from `head`."""
+    r = np.random.default_rng(100 + S)
+    R, C = 37, 256
+    U = r.normal(0, 0.15, size=(R, 4, C)).astype(np.float32)
+    seq = r.normal(size=(R, S, C)).astype(np.float32)              # physical slot order
+    temb = r.normal(0, 0.5, size=(S, C)).astype(np.float32)        # indexed by LOGICAL position
+    ma = r.uniform(size=(R, S)) < 0.3                              # physical slot order, like the ring
+    mb = r.uniform(size=(R, S)) < 0.3
+    ma[0] = True                                                   # nothing attended: zeros, valid = 0
+    ma[1] = mb[1] = False
+    ma[2] = True; ma[2, (head + S - 1) % S] = False; mb[2] = False  # only the last logical slot
+    phys = (head + np.arange(S)) % S                               # logical j -> slot
+    key = seq[:, phys].astype(np.float64) + temb[None].astype(np.float64)
+    sc = np.einsum("rhc,rjc->rhj", U.astype(np.float64), key)
+    ign = (ma | mb)[:, phys]
+    sc = np.where(ign[:, None, :], -np.inf, sc)
+    mx = np.max(sc, -1, keepdims=True)
+    w = np.where(np.isfinite(mx), np.exp(sc - np.where(np.isfinite(mx), mx, 0.0)), 0.0)
+    den = w.sum(-1, keepdims=True)
+    w = np.divide(w, den, out=np.zeros_like(w), where=den > 0)
+    want = np.einsum("rhj,rjc->rhc", w, seq[:, phys].astype(np.float64))
+    valid = ~ign.all(-1)
+    lib = hip.load()
+    try:
+        for mode in (1, 4):
+            lib.lbm_hip_debug_set(3, mode)
+            got, v = hip.attn_readout(torch.from_numpy(U).cuda(), torch.from_numpy(seq).cuda(), S, ring_head=head,
+                                      temb=torch.from_numpy(temb).cuda(), mask_a=torch.from_numpy(ma).cuda().to(torch.uint8),
+                                      mask_b=torch.from_numpy(mb).cuda().to(torch.uint8), want_valid=True)
+            assert (v.bool().cpu().numpy() == valid).all(), f"mode {mode}"
+            err = np.abs(got.cpu().numpy().astype(np.float64) - want).max()
+            assert err < 2e-5, f"mode {mode}: {err}"
+            got2 = hip.attn_readout(torch.from_numpy(U).cuda(), torch.from_numpy(seq).cuda(), S, ring_head=head)   # no masks, no temb
+            sc2 = np.einsum("rhc,rjc->rhj", U.astype(np.float64), seq.astype(np.float64))
+            w2 = np.exp(sc2 - sc2.max(-1, keepdims=True)); w2 /= w2.sum(-1, keepdims=True)
+            want2 = np.einsum("rhj,rjc->rhc", w2, seq.astype(np.float64))
+            assert np.abs(got2.cpu().numpy() - want2).max() < 2e-5, f"mode {mode} plain"
+    finally:
+        lib.lbm_hip_debug_set(3, 0)
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # step level
 # ---------------------------------------------------------------------------------------------------------------

@@ -520,6 +520,7 @@ struct Step {
 
 }  // namespace lbm
 
+namespace lbm { extern int g_corr_variant; }
 using namespace lbm;
 
 extern "C" {
@@ -638,6 +639,10 @@ int lbm_hip_maxpool3x3s2_nhwc(const float* x, float* y, int32_t B, int32_t H, in
 }
 
 int lbm_hip_debug_set(int32_t key, int32_t value) {
+  if (key == 9) {
+    lbm::g_corr_variant = value;
+    return 0;
+  }
   if (key == 1) {
     gemm16_force_tile(value);
     return 0;

@@ -14,6 +14,8 @@ rows = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 hip.load().lbm_hip_debug_set(7, rows)
 if len(sys.argv) > 3:
     hip.load().lbm_hip_debug_set(8, int(sys.argv[3]))
+if len(sys.argv) > 4:
+    hip.load().lbm_hip_debug_set(9, int(sys.argv[4]))
 T, H, W = 16, 240, 320
 video = synthetic_video(T, H, W, seed=21).cuda()
 frames = [video[:, t].contiguous() for t in range(T)]

@@ -1,6 +1,7 @@
 """Block correlation-map kernel (debug key 9 = 1) alone on one stream, a chain of small products on another: does its output
 ever differ from its own serial output?  Tokens alternate between two fixed pyramids, so a stale norm or row would show.
-usage: corr_repro.py [iterations=300] [variant=1] [busy=1]"""
+usage: corr_repro.py [iterations=300] [variant=1] [busy=1] [fresh=0]
+fresh = 1: the pyramid is copied into ONE buffer on the same stream right before every call (a producer kernel just before)."""
 import sys
 
 import torch
@@ -11,6 +12,7 @@ from lbm_amd import hip  # noqa: E402
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 variant = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 busy = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+fresh = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 h, w = 96, 128
 P0 = h * w
 L = P0 + P0 // 4 + P0 // 16 + P0 // 64
@@ -33,13 +35,16 @@ wt = torch.randn(1024, 256, device="cuda") * 0.05
 bias = torch.zeros(1024, device="cuda")
 bad = 0
 worst = 0.0
+T = torch.empty_like(toks[0])
 for it in range(iters):
     if busy:
         with torch.cuda.stream(A):
             for _ in range(24):
                 hip.linear(x, wt, bias)
     with torch.cuda.stream(B):
-        F = hip.corr_maps(toks[it & 1], mix, 3, h, w)
+        if fresh:
+            T.copy_(toks[it & 1])
+        F = hip.corr_maps(T if fresh else toks[it & 1], mix, 3, h, w)
         d = (F - ref[it & 1]).abs().amax()
     B.synchronize()
     if float(d) != 0.0:
@@ -47,4 +52,4 @@ for it in range(iters):
         worst = max(worst, float(d))
 torch.cuda.synchronize()
 lib.lbm_hip_debug_set(9, 0)
-print(f"variant {variant}, busy {busy}: {bad} of {iters} outputs differ from the serial output (max abs diff {worst:.3g})")
+print(f"variant {variant}, busy {busy}, fresh {fresh}: {bad} of {iters} outputs differ from the serial output (max abs diff {worst:.3g})")

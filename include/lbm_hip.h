@@ -362,6 +362,9 @@ int lbm_hip_profile_end(lbm_hip_profile_entry* out, int32_t cap);
 
 /* tuning / debugging knob (process-wide): key 1 = force the split-GEMM tiling (0 auto, 1..n see gemm16.hip) */
 int lbm_hip_debug_set(int32_t key, int32_t value);
+/* the same for pointer-valued knobs: key 1 = device buffer (768 floats per 2x2 cell block) that correlation-map variant 2
+ * (debug key 9 = 2) fills with what each wave loaded and computed -- reproduction aid; NULL = off */
+int lbm_hip_debug_ptr(int32_t key, void* p);
 
 /* debugging aid for parity tests: byte offset of a named intermediate inside the workspace, or -1 */
 int64_t lbm_hip_step_workspace_offset(const lbm_hip_step_desc* d, const char* name);

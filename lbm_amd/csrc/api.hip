@@ -520,7 +520,7 @@ struct Step {
 
 }  // namespace lbm
 
-namespace lbm { extern int g_corr_variant; }
+namespace lbm { extern int g_corr_variant; extern int g_corr_skip_norm; extern float* g_corr_trace; }
 using namespace lbm;
 
 extern "C" {
@@ -643,6 +643,10 @@ int lbm_hip_debug_set(int32_t key, int32_t value) {
     lbm::g_corr_variant = value;
     return 0;
   }
+  if (key == 10) {
+    lbm::g_corr_skip_norm = value;
+    return 0;
+  }
   if (key == 1) {
     gemm16_force_tile(value);
     return 0;
@@ -676,6 +680,15 @@ int lbm_hip_debug_set(int32_t key, int32_t value) {
     return 0;
   }
   set_error("debug_set: unknown key %d", key);
+  return -1;
+}
+
+int lbm_hip_debug_ptr(int32_t key, void* p) {
+  if (key == 1) {
+    lbm::g_corr_trace = (float*)p;
+    return 0;
+  }
+  set_error("debug_ptr: unknown key %d", key);
   return -1;
 }
 

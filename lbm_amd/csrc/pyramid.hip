@@ -11,8 +11,12 @@
 //  * topk_rows      — transformer.py:307-308 + coord_utils.py:4-29: top-k cells of each correlation row
 //                     (ties → lowest index) and their cell centres in network pixels.
 #include "pyramid.hpp"
+#define LBM_CB_NS cb
+#include "corr_block.inc"
 
 namespace lbm {
+using namespace cb;
+int launch_corr_block_nopk(const void* args, unsigned blocks, hipStream_t stream);   // pyramid_nopk.hip
 
 // ------------------------------------------------------------------------------------------------
 // also used (with `toks`) to emit the split-plane twin of the whole token buffer, level 0 included
@@ -23,17 +27,6 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
     const long long row = (i / P0) * L + (i % P0);   // level-0 rows of stream i / P0
     st4_split(xs, plane, row * LBM_C + lane * 4, ld4(x + row * LBM_C + lane * 4));
   }
-}
-
-// bilinear source index/weights of F.interpolate(align_corners=False) from size `in` to `in << lvl`
-__device__ __forceinline__ void up_coeff(int dst, int lvl, int in, int& i0, int& i1, float& l0, float& l1) {
-  const float scale = 1.0f / (float)(1 << lvl);
-  float src = scale * ((float)dst + 0.5f) - 0.5f;
-  if (src < 0.f) src = 0.f;
-  i0 = (int)src;
-  i1 = i0 + (i0 < in - 1 ? 1 : 0);
-  l1 = src - (float)i0;
-  l0 = 1.0f - l1;
 }
 
 // One workgroup per 8x8 block of level-0 cells, one wave per 4x4 quadrant, lane = 4 channels: the 16 level-0 rows of
@@ -182,15 +175,6 @@ __global__ __launch_bounds__(256) void inv_norm_kernel(const float* __restrict__
   }
 }
 
-struct CorrMapArgs {
-  const float* tok;     // [B, L, 256]
-  const float* inv;     // [B, L]
-  float* F;             // [n_layers, B, P0, 256]
-  float wmix[8][4];     // per layer: corr_conv weights (w0..w3); the +1 residual is added here
-  int n_layers, B, h, w, L;
-  int split;            // 1: F is written as split f16 planes, per layer [hi: B*P0*256][lo: B*P0*256]
-};
-
 __global__ __launch_bounds__(256) void corr_maps_kernel(CorrMapArgs a) {
   const int lane = threadIdx.x & 63;
   const int P0 = a.h * a.w;
@@ -246,114 +230,9 @@ __global__ __launch_bounds__(256) void corr_maps_kernel(CorrMapArgs a) {
   }
 }
 
-// One wave per 2x2 block of level-0 cells (aligned to 2), lane = 4 channels.  The bilinear footprints of the four cells
-// overlap almost entirely: on level 1 they cover a 3x3 patch of coarse cells, on levels 2 and 3 the SAME 2x2 patch (a
-// 2-aligned pair of fine cells never straddles a coarse source pair), so a block needs 4 + 9 + 4 + 4 = 21 normalised rows
-// where cell-by-cell evaluation fetched 52 -- the kernel is bound by what it pulls through the L2, not by HBM.  All 21
-// row loads and their norms are requested before anything is used.  Weights come from up_coeff per cell, positions from
-// the patch: at the borders up_coeff's clamped pair (i0, i1) and the patch pair differ only where the weight is 0.
-// 785 vs 1245 us at 64 streams of 96x128 cells -- but NOT the default (debug key 9 = 1 selects it): beside the per-point
-// chain of the frame pipeline its output differed from the serial run's in ~13 % of the frames (a few 2x2 blocks, small
-// relative error), like the fused feed-forward before it was given the CU to itself; see DESIGN.md section 8.
-__global__ __launch_bounds__(256) void corr_maps_block_kernel(CorrMapArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int P0 = a.h * a.w;
-  const int bw = a.w >> 1, bh = a.h >> 1;
-  const long long total = (long long)a.B * bh * bw;
-  for (long long blk = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); blk < total;
-       blk += (long long)gridDim.x * 4) {
-    const int b = (int)(blk / (bh * bw));
-    const int rem = (int)(blk - (long long)b * (bh * bw));
-    const int y0 = (rem / bw) * 2, x0 = (rem % bw) * 2;
-    const float* tb = a.tok + (long long)b * a.L * LBM_C + lane * 4;
-    const float* ib = a.inv + (long long)b * a.L;
-    auto nrow = [&](int t) {                      // normalised row t of this stream's token buffer
-      const float4 v = ld4(tb + (long long)t * LBM_C);
-      const float s = ib[t];
-      return make_float4(v.x * s, v.y * s, v.z * s, v.w * s);
-    };
-    // ---- all rows of the block ----
-    float4 c0[2][2], p1[3][3], p2[2][2], p3[2][2];
-#pragma unroll
-    for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-      for (int dx = 0; dx < 2; ++dx) c0[dy][dx] = nrow((y0 + dy) * a.w + x0 + dx);
-    {
-      const int hl = a.h >> 1, wl = a.w >> 1, st = P0;
-      const int iy = y0 >> 1, ix = x0 >> 1;
-      const int ry[3] = {max(iy - 1, 0), iy, min(iy + 1, hl - 1)};
-      const int rx[3] = {max(ix - 1, 0), ix, min(ix + 1, wl - 1)};
-#pragma unroll
-      for (int u = 0; u < 3; ++u)
-#pragma unroll
-        for (int v = 0; v < 3; ++v) p1[u][v] = nrow(st + ry[u] * wl + rx[v]);
-    }
-    int ya[2], yb[2], xa[2], xb[2];               // source pairs on levels 2 and 3 (shared by the block's cells)
-    float wy[4][2][2], wx[4][2][2];               // [level][d][0/1] bilinear weights of row y0 + d / column x0 + d
-    {
-      int start = P0 + (a.h >> 1) * (a.w >> 1);
-#pragma unroll
-      for (int l = 2; l < 4; ++l) {
-        const int hl = a.h >> l, wl = a.w >> l;
-        int t0, t1;
-        up_coeff(y0, l, hl, ya[l - 2], yb[l - 2], wy[l][0][0], wy[l][0][1]);
-        up_coeff(y0 + 1, l, hl, t0, t1, wy[l][1][0], wy[l][1][1]);
-        up_coeff(x0, l, wl, xa[l - 2], xb[l - 2], wx[l][0][0], wx[l][0][1]);
-        up_coeff(x0 + 1, l, wl, t0, t1, wx[l][1][0], wx[l][1][1]);
-        float4(&pp)[2][2] = l == 2 ? p2 : p3;
-        pp[0][0] = nrow(start + ya[l - 2] * wl + xa[l - 2]);
-        pp[0][1] = nrow(start + ya[l - 2] * wl + xb[l - 2]);
-        pp[1][0] = nrow(start + yb[l - 2] * wl + xa[l - 2]);
-        pp[1][1] = nrow(start + yb[l - 2] * wl + xb[l - 2]);
-        start += hl * wl;
-      }
-      int t0, t1;
-#pragma unroll
-      for (int d = 0; d < 2; ++d) {
-        up_coeff(y0 + d, 1, a.h >> 1, t0, t1, wy[1][d][0], wy[1][d][1]);
-        up_coeff(x0 + d, 1, a.w >> 1, t0, t1, wx[1][d][0], wx[1][d][1]);
-      }
-    }
-    auto bil = [](const float4& v00, const float4& v01, const float4& v10, const float4& v11, float ly0, float ly1, float lx0,
-                  float lx1) {
-      float4 r;
-      r.x = ly0 * (lx0 * v00.x + lx1 * v01.x) + ly1 * (lx0 * v10.x + lx1 * v11.x);
-      r.y = ly0 * (lx0 * v00.y + lx1 * v01.y) + ly1 * (lx0 * v10.y + lx1 * v11.y);
-      r.z = ly0 * (lx0 * v00.z + lx1 * v01.z) + ly1 * (lx0 * v10.z + lx1 * v11.z);
-      r.w = ly0 * (lx0 * v00.w + lx1 * v01.w) + ly1 * (lx0 * v10.w + lx1 * v11.w);
-      return r;
-    };
-#pragma unroll
-    for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-      for (int dx = 0; dx < 2; ++dx) {
-        float4 lv[4];
-        lv[0] = c0[dy][dx];
-        // level 1: row y0 + dy reads patch rows (dy, dy + 1), column x0 + dx patch columns (dx, dx + 1)
-        lv[1] = bil(p1[dy][dx], p1[dy][dx + 1], p1[dy + 1][dx], p1[dy + 1][dx + 1], wy[1][dy][0], wy[1][dy][1], wx[1][dx][0],
-                    wx[1][dx][1]);
-        lv[2] = bil(p2[0][0], p2[0][1], p2[1][0], p2[1][1], wy[2][dy][0], wy[2][dy][1], wx[2][dx][0], wx[2][dx][1]);
-        lv[3] = bil(p3[0][0], p3[0][1], p3[1][0], p3[1][1], wy[3][dy][0], wy[3][dy][1], wx[3][dx][0], wx[3][dx][1]);
-        const int p = (y0 + dy) * a.w + x0 + dx;
-        for (int i = 0; i < a.n_layers; ++i) {
-          const float w0 = a.wmix[i][0] + 1.0f, w1 = a.wmix[i][1], w2 = a.wmix[i][2], w3 = a.wmix[i][3];
-          float4 o;
-          o.x = w0 * lv[0].x + w1 * lv[1].x + w2 * lv[2].x + w3 * lv[3].x;
-          o.y = w0 * lv[0].y + w1 * lv[1].y + w2 * lv[2].y + w3 * lv[3].y;
-          o.z = w0 * lv[0].z + w1 * lv[1].z + w2 * lv[2].z + w3 * lv[3].z;
-          o.w = w0 * lv[0].w + w1 * lv[1].w + w2 * lv[2].w + w3 * lv[3].w;
-          if (a.split) {
-            const long long plane = (long long)a.B * P0 * LBM_C;
-            st4_split(reinterpret_cast<_Float16*>(a.F) + (long long)i * 2 * plane, plane, ((long long)b * P0 + p) * LBM_C + lane * 4, o);
-          } else {
-            st4(a.F + (((long long)i * a.B + b) * P0 + p) * LBM_C + lane * 4, o);
-          }
-        }
-      }
-  }
-}
-
-int g_corr_variant = 0;   // tuning / reproduction knob (lbm_hip_debug_set key 9): 1 = corr_maps_block_kernel
+int g_corr_variant = 0;   // tuning / reproduction knob (lbm_hip_debug_set key 9): 1 = corr_maps_block_kernel, 2 = the same + trace
+float* g_corr_trace = nullptr;   // lbm_hip_debug_ptr key 1
+int g_corr_skip_norm = 0;        // debug key 10: 1 = the caller's inv_norm buffer is used as it is (hypothesis tests, scripts/stale_offline.py)
 
 int corr_maps(const float* tokens, float* inv_norm, float* F, const float* wmix_host, int n_layers, int B, int h, int w,
               bool split, hipStream_t stream) {
@@ -365,7 +244,7 @@ int corr_maps(const float* tokens, float* inv_norm, float* F, const float* wmix_
   long long rows = (long long)B * L;
   long long blocks = (rows + 3) / 4;
   if (blocks > 16384) blocks = 16384;
-  {
+  if (!g_corr_skip_norm) {
     ProfScope prof("inv_norm", stream, 0.0, 4.0 * LBM_C * rows);
     hipLaunchKernelGGL(inv_norm_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, tokens, inv_norm, rows);
   }
@@ -377,10 +256,20 @@ int corr_maps(const float* tokens, float* inv_norm, float* F, const float* wmix_
   blocks = ((long long)B * P0 + 3) / 4;
   if (blocks > 16384) blocks = 16384;
   ProfScope prof("corr_maps", stream, 0.0, 4.0 * LBM_C * B * ((double)L + (double)n_layers * P0));
-  if (g_corr_variant == 1) {
+  a.trace = g_corr_trace;
+  if (g_corr_variant >= 1 && g_corr_variant <= 5) {
     blocks = ((long long)B * (P0 / 4) + 3) / 4;      // one wave per 2x2 block of cells
     if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(corr_maps_block_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    if (g_corr_variant == 2)
+      hipLaunchKernelGGL(corr_maps_block_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    else if (g_corr_variant == 3)
+      hipLaunchKernelGGL(corr_maps_block_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    else if (g_corr_variant == 4)
+      hipLaunchKernelGGL(corr_maps_block_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    else if (g_corr_variant == 5)
+      launch_corr_block_nopk(&a, (unsigned)blocks, stream);
+    else
+      hipLaunchKernelGGL(corr_maps_block_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
   } else {
     hipLaunchKernelGGL(corr_maps_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
   }

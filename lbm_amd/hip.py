@@ -28,6 +28,7 @@ EXPORTS = (
     "lbm_hip_profile_begin", "lbm_hip_profile_end", "lbm_hip_split_planes", "lbm_hip_debug_set", "lbm_hip_linear_ss",
     "lbm_hip_conv2d_nhwc_ss", "lbm_hip_maxpool3x3s2_nhwc_s", "lbm_hip_upcat_s", "lbm_hip_pyramid_s",
     "lbm_hip_update_points", "lbm_hip_encoder_tail", "lbm_hip_pack_fragment_major", "lbm_hip_ffn_slabs",
+    "lbm_hip_debug_ptr",
 )
 
 
@@ -156,6 +157,7 @@ def load() -> C.CDLL:
     lib.lbm_hip_linear_ss.argtypes = [C.POINTER(LinearSSDesc), C.c_void_p]
     lib.lbm_hip_split_planes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.lbm_hip_profile_end.argtypes = [C.POINTER(ProfileEntry), C.c_int32]
+    lib.lbm_hip_debug_ptr.argtypes = [C.c_int32, C.c_void_p]
     _lib = lib
     return lib
 

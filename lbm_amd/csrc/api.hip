@@ -520,7 +520,7 @@ struct Step {
 
 }  // namespace lbm
 
-namespace lbm { extern int g_corr_variant; extern int g_corr_skip_norm; extern float* g_corr_trace; }
+namespace lbm { extern int g_corr_variant; extern int g_corr_skip_norm; extern int g_ln_serial; extern int g_ffn_claim; extern float* g_corr_trace; }
 using namespace lbm;
 
 extern "C" {
@@ -645,6 +645,14 @@ int lbm_hip_debug_set(int32_t key, int32_t value) {
   }
   if (key == 10) {
     lbm::g_corr_skip_norm = value;
+    return 0;
+  }
+  if (key == 11) {
+    lbm::g_ln_serial = value;
+    return 0;
+  }
+  if (key == 12) {
+    lbm::g_ffn_claim = value;
     return 0;
   }
   if (key == 1) {

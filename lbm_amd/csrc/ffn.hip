@@ -60,7 +60,7 @@ struct FfnDev {
 constexpr int kC = 256, kHid = 1024, kRows = 32;
 constexpr int kAP = kC + 8;                 // LDS pitch (halves) of the activation tile: 528 B = 4 banks past a multiple of 64
 
-template <int CH, int NPL>
+template <int CH, int NPL, bool CLAIM>
 __global__ __launch_bounds__(256) void ffn_fused_kernel(FfnDev a) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int NT1 = CH / 32 / 4;           // hidden tiles per wave
@@ -72,12 +72,12 @@ __global__ __launch_bounds__(256) void ffn_fused_kernel(FfnDev a) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int c = blockIdx.x, m0 = blockIdx.y * kRows;
-  // The wave claims the SIMD's whole register file (256 + 256), so no wave of another kernel is ever resident beside it.
-  // With ~270 registers a wave of a kernel running on another HIP stream could share the SIMD, and then -- only then --
-  // roughly one frame in twenty of the frame pipeline (encoder of frame t+1 beside this chain) came out with a few points
-  // perturbed at the 2^-11 level (rows 0..2 of a 32-row tile, lanes 0..31 of the first accumulator registers); alone on
-  // the SIMD: 0 of 600 frames.  Any delay added to the kernel hid it as well; the cause was not established.
-  asm volatile("" ::: "v255", "a255");
+  // CLAIM (lbm_hip_debug_set key 12 = 1; off by default): the wave claims the SIMD's whole register file (256 + 256), so no
+  // wave of another kernel is resident beside it.  Round 1 shipped this as a guard: built with packed-fp32 instructions the
+  // kernel came out with a few points perturbed at the 2^-11 level in ~1 frame of 20 of the frame pipeline.  The library is
+  // now built without packed-fp32 instructions (Makefile) and the kernel screens 0 of 1500 frames
+  // without the claim; same speed either way (13.2 us per launch at 1024 rows).
+  if constexpr (CLAIM) asm volatile("" ::: "v255", "a255");
 
   // ---- every weight fragment this wave will need, requested up front ----
   half8 b1h[NT1][KS1], b1l[NT1][KS1];
@@ -186,6 +186,8 @@ __global__ __launch_bounds__(256) void ffn_fused_kernel(FfnDev a) {
 #endif
 }
 
+int g_ffn_claim = 0;   // debug key 12: 1 = the wave claims the whole register file (see the kernel)
+
 int ffn_fused(const FfnArgs& f, hipStream_t stream) {
   if (f.M == 0) return 0;
   LBM_REQUIRE(f.A && f.F1 && f.b1 && f.F2 && f.slabs && f.M > 0, "ffn_fused: null argument");
@@ -201,8 +203,13 @@ int ffn_fused(const FfnArgs& f, hipStream_t stream) {
   const double flops = 4.0 * f.M * kC * kHid;
   const double bytes = 2.0 * f.planes * (f.M * kC + 2.0 * kC * kHid) + 4.0 * f.M * kC * (kHid / f.chunk);
   ProfScope prof(f.planes == 2 ? "ffn_fused_ss" : "ffn_fused_sh", stream, flops, bytes);
-  if (f.planes == 2) hipLaunchKernelGGL((ffn_fused_kernel<128, 2>), grid, dim3(256), 0, stream, d);
-  else hipLaunchKernelGGL((ffn_fused_kernel<128, 1>), grid, dim3(256), 0, stream, d);
+  if (g_ffn_claim) {
+    if (f.planes == 2) hipLaunchKernelGGL((ffn_fused_kernel<128, 2, true>), grid, dim3(256), 0, stream, d);
+    else hipLaunchKernelGGL((ffn_fused_kernel<128, 1, true>), grid, dim3(256), 0, stream, d);
+  } else {
+    if (f.planes == 2) hipLaunchKernelGGL((ffn_fused_kernel<128, 2, false>), grid, dim3(256), 0, stream, d);
+    else hipLaunchKernelGGL((ffn_fused_kernel<128, 1, false>), grid, dim3(256), 0, stream, d);
+  }
   return check_launch("ffn_fused");
 }
 

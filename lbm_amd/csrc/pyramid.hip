@@ -16,7 +16,7 @@
 
 namespace lbm {
 using namespace cb;
-int launch_corr_block_nopk(const void* args, unsigned blocks, hipStream_t stream);   // pyramid_nopk.hip
+int launch_corr_block_packed(const void* args, int mode, unsigned blocks, hipStream_t stream);   // corr_block_pk.hip
 
 // ------------------------------------------------------------------------------------------------
 // also used (with `toks`) to emit the split-plane twin of the whole token buffer, level 0 included
@@ -230,9 +230,12 @@ __global__ __launch_bounds__(256) void corr_maps_kernel(CorrMapArgs a) {
   }
 }
 
-int g_corr_variant = 0;   // tuning / reproduction knob (lbm_hip_debug_set key 9): 1 = corr_maps_block_kernel, 2 = the same + trace
+// lbm_hip_debug_set key 9: 0 (default) / 5 = 2x2-block kernel of THIS file (no packed-fp32 instructions); 6 = cell-by-cell
+// kernel; 1..4 = the block kernel built WITH packed-fp32 instructions (corr_block_pk.hip: 1 plain -- the form that showed
+// wrong cells beside a second queue --, 2 + trace, 3 every loaded row tied behind its wait, 4 the same + idle cycles)
+int g_corr_variant = 0;
 float* g_corr_trace = nullptr;   // lbm_hip_debug_ptr key 1
-int g_corr_skip_norm = 0;        // debug key 10: 1 = the caller's inv_norm buffer is used as it is (hypothesis tests, scripts/stale_offline.py)
+int g_corr_skip_norm = 0;        // debug key 10: 1 = the caller's inv_norm buffer is used as it is (scripts/stale_offline.py)
 
 int corr_maps(const float* tokens, float* inv_norm, float* F, const float* wmix_host, int n_layers, int B, int h, int w,
               bool split, hipStream_t stream) {
@@ -257,21 +260,15 @@ int corr_maps(const float* tokens, float* inv_norm, float* F, const float* wmix_
   if (blocks > 16384) blocks = 16384;
   ProfScope prof("corr_maps", stream, 0.0, 4.0 * LBM_C * B * ((double)L + (double)n_layers * P0));
   a.trace = g_corr_trace;
-  if (g_corr_variant >= 1 && g_corr_variant <= 5) {
+  if (g_corr_variant == 6) {
+    hipLaunchKernelGGL(corr_maps_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+  } else {
     blocks = ((long long)B * (P0 / 4) + 3) / 4;      // one wave per 2x2 block of cells
     if (blocks > 16384) blocks = 16384;
-    if (g_corr_variant == 2)
-      hipLaunchKernelGGL(corr_maps_block_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
-    else if (g_corr_variant == 3)
-      hipLaunchKernelGGL(corr_maps_block_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
-    else if (g_corr_variant == 4)
-      hipLaunchKernelGGL(corr_maps_block_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
-    else if (g_corr_variant == 5)
-      launch_corr_block_nopk(&a, (unsigned)blocks, stream);
+    if (g_corr_variant >= 1 && g_corr_variant <= 4)
+      launch_corr_block_packed(&a, g_corr_variant - 1, (unsigned)blocks, stream);
     else
       hipLaunchKernelGGL(corr_maps_block_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
-  } else {
-    hipLaunchKernelGGL(corr_maps_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
   }
   return check_launch("corr_maps");
 }

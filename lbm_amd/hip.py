@@ -15,7 +15,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 
 _HERE = Path(__file__).resolve().parent
-_LIB_PATH = _HERE / "liblbm_hip.so"
+_LIB_PATH = Path(os.environ.get("LBM_AMD_LIB", _HERE / "liblbm_hip.so"))     # LBM_AMD_LIB: A/B builds of the library (development)
 _HEADER = _HERE.parent / "include" / "lbm_hip.h"
 MAX_LAYERS = 8
 

@@ -1,5 +1,5 @@
 """Frame pipeline: rate of wrong correlation-map cells per kernel variant, variants interleaved on ONE box (the rate depends on
-the box).  usage: stale_variants.py reps v1,v2,...   (debug key 9 values; 0 = cell-by-cell kernel, 1 = 2x2-block kernel,
+the box).  usage: stale_variants.py reps v1,v2,...   (debug key 9 values; 0 / 5 = the product 2x2-block kernel (no packed-fp32 instructions), 6 = cell-by-cell kernel, 1 = block kernel built with packed-fp32,
 3 = block kernel with every loaded row tied behind its wait, 4 = the same + 16 idle cycles after each wait)"""
 import sys
 

@@ -2,8 +2,11 @@
  *
  * This is the drop-in boundary of the hot path: plain pointers and sizes, no torch types.  Every
  * pointer is DEVICE memory owned by the caller (in this repo: PyTorch-allocated tensors, passed as
- * tensor.data_ptr()); the library allocates nothing, keeps no hidden state (the ring-buffer head is a
- * caller-held int) and enqueues all work on the caller's HIP stream without synchronising.
+ * tensor.data_ptr()); the library allocates nothing, keeps no tracking state (the ring-buffer head is a
+ * caller-held int) and enqueues all work on the caller's HIP stream without synchronising.  Process-wide state it does
+ * keep: the debug knobs (lbm_hip_debug_set / _ptr), the profiling records between lbm_hip_profile_begin / _end, and four
+ * timing-disabled HIP events created on first use by lbm_hip_track_step when n_aux_streams > 0 (fork / join of the
+ * auxiliary streams; concurrent calls with auxiliary streams from several host threads are therefore not supported).
  * All functions return 0 on success and a negative value on error; the message is available from
  * lbm_hip_last_error() (thread-local).  Nothing throws across the ABI.
  *
@@ -83,7 +86,7 @@ int lbm_hip_l2norm(const float* X, int64_t ldx, float* Y, int64_t ldy, int64_t r
  * Logical position j lives in physical slot (ring_head + j) % S; masks are in physical order,
  * non-zero = ignore; valid[r] = 0 when every position of row r is ignored (then out[r] = 0).
  * Replaces the nn.MultiheadAttention calls of transformer.py:272, 294, 333 (together with two
- * lbm_hip_linear calls using weights folded by lbm_amd/packing.py).                              */
+ * lbm_hip_linear calls using weights folded by lbm_amd/engine.py: fold_attention / TrackerWeights).                              */
 int lbm_hip_attn_readout(const float* U, const float* seq, int64_t point_stride, int64_t slot_stride,
                          int32_t S, int32_t ring_head, const float* temb, const uint8_t* mask_a,
                          const uint8_t* mask_b, float* out, uint8_t* valid, int32_t R, lbm_stream_t stream);
@@ -165,7 +168,7 @@ int lbm_hip_pyramid_s(float* tokens, void* tokens_s, int64_t tokens_plane, int32
 /* ---------------------------------------------------------------------------------------------
  * Whole tracking step = LBMTransformer.forward (transformer.py:74-151) + the state roll and output
  * scaling of LBM_online.online_forward (lbm_online.py:143-156), enqueued as one call.
- * Weight table layout: see the LBM_W_* indices below (built by lbm_amd/packing.py).             */
+ * Weight table layout: see the LBM_W_* indices below (built by lbm_amd/engine.py: TrackerWeights).             */
 #define LBM_W_ATTN_G 0      /* [1024,256]  per-head Wk_h^T Wq_h / 8, heads stacked           */
 #define LBM_W_ATTN_GB 1     /* [1024]                                                         */
 #define LBM_W_ATTN_TEMB 2   /* [M,256] time embedding of the past slots (NULL for lattice update) */

@@ -1,3 +1,7 @@
-"""Reference import path lbm.utils.tracker_utils: the three helpers the object tracker uses (tracker_utils.py:53, 727, 736).
-BaseTracker / KalmanFilter (tracker_utils.py:242-725) are not used by any caller of the tracking path and are not provided."""
-from lbm_amd.object_tracker import bbox_overlaps, check_points_in_box, sample_points_in_box  # noqa: F401
+"""Import-path twin of lbm/utils/tracker_utils.py.  With the reference checkout and ``addict`` (tracker_utils.py:8) available
+the reference's own file is executed here (BaseTracker, KalmanFilter, bbox helpers); otherwise the three helpers the object
+tracker uses (tracker_utils.py:53, 727, 736) come from lbm_amd/object_tracker.py."""
+from lbm_amd._refshim import delegate as _delegate
+
+if not _delegate(globals()):
+    from lbm_amd.object_tracker import bbox_overlaps, check_points_in_box, sample_points_in_box  # noqa: F401

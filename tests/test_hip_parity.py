@@ -744,7 +744,7 @@ def test_cached_first_layer_queries_are_refreshed_when_the_query_changes(hip):
 
 
 def test_graph_replay_and_point_parallel_streams_match_the_plain_eager_step(hip, monkeypatch):
-    """B = 1, N = 1024: the default path (HIP-graph replay per ring head, per-point chain on 4 concurrent streams)
+    """B = 1, N = 1024: the opt-in knobs (LBM_AMD_GRAPH: HIP-graph replay per ring head; LBM_AMD_AUX_STREAMS: per-point chain on 4 concurrent streams)
     against the plain single-stream eager path over 15 frames (the ring wraps: M = 12)."""
     from lbm_amd.synth import synthetic_video, grid_queries
     T, H, W = 16, 240, 320

@@ -345,6 +345,19 @@ int lbm_hip_update_points(const uint8_t* remove_mask, int32_t N_old, const uint8
                           const uint8_t* old_mem, const float* new_query, float* query, float* stream_mem, float* coll_mem,
                           uint8_t* vis_mask, uint8_t* mem_mask, int32_t* scratch, lbm_stream_t stream);
 
+/* lbm_hip_update_points for callers that cannot allocate -- code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc.  No counterpart in the reference.  Same arguments and results, minus `scratch`: the scan's N_old + 1
+ * ints live in a static device array of the library (LBM_UPDATE_STATIC_MAX_POINTS + 1 ints = 256 KiB, held by every GPU the
+ * library runs on until the process ends; its address is looked up once per device, on the first call there, with
+ * hipGetSymbolAddress).  The call allocates nothing and frees nothing.  N_old above the maximum is refused (use
+ * lbm_hip_update_points).  Nothing in the array needs clearing between calls (the scan writes every entry the gather reads),
+ * but every call on a GPU shares that GPU's array: calls that overlap on one GPU (two streams, two host threads) race.  */
+#define LBM_UPDATE_STATIC_MAX_POINTS 65536
+int lbm_hip_update_points_static(const uint8_t* remove_mask, int32_t N_old, const uint8_t* update_mask, int32_t N_new, int32_t M,
+                                 const float* old_query, const float* old_stream, const float* old_coll, const uint8_t* old_vis,
+                                 const uint8_t* old_mem, const float* new_query, float* query, float* stream_mem, float* coll_mem,
+                                 uint8_t* vis_mask, uint8_t* mem_mask, lbm_stream_t stream);
+
 /* bytes of workspace lbm_hip_track_step needs for this geometry (only B, N, M, n_layers, topk, net_* are read) */
 uint64_t lbm_hip_step_workspace_bytes(const lbm_hip_step_desc* d);
 int lbm_hip_track_step(const lbm_hip_step_desc* d, lbm_stream_t stream);

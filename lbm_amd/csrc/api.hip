@@ -799,6 +799,17 @@ int lbm_hip_update_points(const uint8_t* remove_mask, int32_t N_old, const uint8
   return update_points(a, (hipStream_t)stream);
 }
 
+int lbm_hip_update_points_static(const uint8_t* remove_mask, int32_t N_old, const uint8_t* update_mask, int32_t N_new, int32_t M,
+                                 const float* old_query, const float* old_stream, const float* old_coll, const uint8_t* old_vis,
+                                 const uint8_t* old_mem, const float* new_query, float* query, float* stream_mem, float* coll_mem,
+                                 uint8_t* vis_mask, uint8_t* mem_mask, lbm_stream_t stream) {
+  UpdatePointsArgs a;
+  a.remove_mask = remove_mask; a.update_mask = update_mask; a.N_old = N_old; a.N_new = N_new; a.M = M;
+  a.old_query = old_query; a.old_stream = old_stream; a.old_coll = old_coll; a.old_vis = old_vis; a.old_mem = old_mem;
+  a.new_query = new_query; a.query = query; a.stream = stream_mem; a.coll = coll_mem; a.vis = vis_mask; a.mem = mem_mask;
+  return update_points_static(a, (hipStream_t)stream);
+}
+
 uint64_t lbm_hip_step_workspace_bytes(const lbm_hip_step_desc* d) {
   StepLayout lay;
   if (build_layout(d, lay)) return 0;

@@ -1,6 +1,9 @@
 // Head read-outs fused with the state update (transformer.py:119-120, 136-138, 147-149;
 // lbm_online.py:143-156).  One wave per point, lane = 4 channels.
 #include "final.hpp"
+#include "../../include/lbm_hip.h"
+
+#include <mutex>
 
 namespace lbm {
 
@@ -158,6 +161,32 @@ int update_points(const UpdatePointsArgs& a, hipStream_t stream) {
   if (check_launch("update_scan")) return -1;
   hipLaunchKernelGGL(update_gather_kernel, dim3((a.N_new + 3) / 4), dim3(256), 0, stream, a);
   return check_launch("update_gather");
+}
+
+// ---- the same edit with the scan's scratch in a static device array (lbm_hip_update_points_static) -----------------------
+// `scratch` below is the HOST-side stand-in of the array: its device address is looked up once per device with
+// hipGetSymbolAddress (each GPU holds its own copy) and only that pointer is ever handed to a kernel.
+static __device__ __align__(256) int scratch[LBM_UPDATE_STATIC_MAX_POINTS + 1];
+static int* g_scratch_ptr[LBM_MAX_DEVICES] = {};
+static std::mutex g_scratch_mutex;
+
+int update_points_static(UpdatePointsArgs a, hipStream_t stream) {
+  LBM_REQUIRE(a.N_old >= 0 && a.N_old <= LBM_UPDATE_STATIC_MAX_POINTS,
+              "update_points_static: N_old = %d exceeds the static scratch (%d points); use lbm_hip_update_points with a caller-provided scratch",
+              a.N_old, LBM_UPDATE_STATIC_MAX_POINTS);
+  int dev = -1;
+  LBM_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < LBM_MAX_DEVICES, "update_points_static: no current device (or index >= %d)", LBM_MAX_DEVICES);
+  {
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[dev] == nullptr) {
+      void* p = nullptr;
+      const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+      LBM_REQUIRE(e == hipSuccess && p != nullptr, "update_points_static: hipGetSymbolAddress failed on device %d: %s", dev, hipGetErrorString(e));
+      g_scratch_ptr[dev] = static_cast<int*>(p);
+    }
+    a.scratch = g_scratch_ptr[dev];
+  }
+  return update_points(a, stream);
 }
 
 }  // namespace lbm

@@ -56,5 +56,8 @@ struct UpdatePointsArgs {
   int* scratch = nullptr;                 // N_old + 1 ints
 };
 int update_points(const UpdatePointsArgs& a, hipStream_t stream);
+// the same with the scan's scratch (N_old + 1 ints) in a static device array of the library: allocates nothing
+constexpr int LBM_MAX_DEVICES = 64;
+int update_points_static(UpdatePointsArgs a, hipStream_t stream);
 
 }  // namespace lbm

@@ -28,7 +28,7 @@ EXPORTS = (
     "lbm_hip_profile_begin", "lbm_hip_profile_end", "lbm_hip_split_planes", "lbm_hip_debug_set", "lbm_hip_linear_ss",
     "lbm_hip_conv2d_nhwc_ss", "lbm_hip_maxpool3x3s2_nhwc_s", "lbm_hip_upcat_s", "lbm_hip_pyramid_s",
     "lbm_hip_update_points", "lbm_hip_encoder_tail", "lbm_hip_pack_fragment_major", "lbm_hip_ffn_slabs",
-    "lbm_hip_debug_ptr",
+    "lbm_hip_debug_ptr", "lbm_hip_update_points_static",
 )
 
 
@@ -145,6 +145,7 @@ def load() -> C.CDLL:
                                       C.c_int32, C.c_int32, C.c_void_p]
     lib.lbm_hip_encoder_tail.argtypes = [C.c_void_p] * 6 + [C.c_int64] + [C.c_int32] * 3 + [C.c_void_p]
     lib.lbm_hip_update_points.argtypes = ([C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 13)
+    lib.lbm_hip_update_points_static.argtypes = ([C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 12)
     lib.lbm_hip_step_workspace_bytes.argtypes = [C.POINTER(StepDesc)]
     lib.lbm_hip_track_step.argtypes = [C.POINTER(StepDesc), C.c_void_p]
     lib.lbm_hip_conv2d_nhwc.argtypes = [C.c_void_p] * 6 + [C.c_int32] * 11 + [C.c_void_p]

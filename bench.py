@@ -6,13 +6,19 @@ One "step" = one full ``online_forward`` (feature encoder + tracker transformer 
 for every stream the rank owns; frames are resident in HBM before the timed region.  Workloads (BASELINE.json
 ``configs``; weights = seeded synthetic checkpoint in the lbm.pt layout, videos = seeded synthetic):
 
-  c2 (default, the configuration the metric is quoted on):  1 stream, 480x854, dense 32x32 grid = 1024 points, M = 12
-  c3:  64 streams x 256 points, 480x854, batched in one step
+  c2 (default at N = 1, the configuration the metric is quoted on):  1 stream, 480x854, dense 32x32 grid = 1024 points, M = 12
+  c3 (default at N > 1: BASELINE config 4 = 64 streams per GPU):     64 streams x 256 points, 480x854, batched in one step
   c5:  1 stream, 1080x1920, dense 100x100 grid = 10 000 points, memory M = 48
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): every rank runs the same workload on its own streams
-(weak scaling; streams are independent, no collective in the data path); the only collective is the RCCL gather of
-the results at the end.  value = points x streams x ranks x K / max-over-ranks wall time.
+The timed region runs strictly SERIAL frames.  The frame pipeline (LBM_online.prefetch: encoder of frame t+1 on a second
+HIP stream) is timed afterwards from the same starting state and reported beside the headline (``frame_pipeline``) with
+``pipeline_bit_identical``: its final tracks and memories compared bit for bit with the serial run's.
+At N = 1 the line also carries ``workloads``: the throughput regime (c3, c5) measured in the same process.
+
+N > 1: ``python bench.py --gpus N`` starts N ranks itself (child ``torch.distributed.run`` before anything touches the
+GPU) unless a launcher already did (WORLD_SIZE set).  Every rank runs the workload on its own streams (weak scaling; streams
+are independent, no collective in the data path); the only collective is the RCCL gather of the results at the end.
+value = points x streams x ranks x K / max-over-ranks wall time.
 """
 from __future__ import annotations
 
@@ -36,6 +42,7 @@ WORKLOADS = {
     "c5": dict(desc="1 stream 1080x1920, dense 100x100 grid (10000 points), memory 48", B=1, grid=100, H=1080, W=1920, M=48, frames=4),
 }
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
+L2_GATHER_PEAK_GBS = 16800.0 # MI355X_MICROARCH.md, memory hierarchy: rows shared by every workgroup served by the XCDs' L2s, 16.8-18.8 TB/s
 F32_MFMA_PEAK_TF = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, exact fp32
 F16_MFMA_PEAK_TF = 2500.0    # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak (the split-precision kernels issue 3 MFMA
                              # flops per algorithmic flop, so their ceiling in algorithmic TFLOP/s is a third of it)
@@ -101,30 +108,148 @@ def cpu_baseline(wl, sd, video, pts, budget_s=20.0):
                       f"{dt:.1f} s; {1000 * dt / frames:.0f} ms/frame"}
 
 
+def step_flops(wl, N, B):
+    """ALGORITHMIC flops of one step: 84.7 MFLOP per point-frame at M = 12 (+1.573 per extra memory slot)
+    and 25.2 GFLOP per stream-frame (encoder + the six value projections)."""
+    return B * N * (84.7e6 + 1.573e6 * (wl["M"] - 12)) + B * 25.2e9
+
+
+def roofline_of(prof, steps_profiled):
+    """Roofline entry of the dominant kernel of a HIP-event profile (None without one)."""
+    if not prof:
+        return None, []
+    dom = max(prof, key=lambda p: p["total_ms"])
+    sec = dom["total_ms"] / 1e3
+    if dom["name"].startswith(("gemm_", "conv_", "ffn_")):
+        ach = dom["flops"] / sec / 1e12            # ALGORITHMIC flops (2 M N K) per second
+        f32 = dom["name"].startswith(("gemm_f32", "conv_f32"))
+        peak = F32_MFMA_PEAK_TF if f32 else F16_MFMA_PEAK_TF
+        roof = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                "mfma_flops_per_algorithmic_flop": 1 if (f32 or dom["name"].startswith(("gemm_sh", "conv_sh", "ffn_fused_sh"))) else 3}
+    elif dom["name"].startswith("msda_sample"):
+        # a gather out of a 16.7 MB map that every workgroup shares: served by the L2s, not by HBM -- priced against the
+        # guide's L2 shared-row rate, reported under bound "hbm" would exceed 1
+        ach = dom["bytes"] / sec / 1e9
+        roof = {"bound": "l2-gather", "achieved": ach, "peak": L2_GATHER_PEAK_GBS, "unit": "GB/s", "frac": ach / L2_GATHER_PEAK_GBS,
+                "traffic": None}
+    else:
+        ach = dom["bytes"] / sec / 1e9
+        roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None}
+    roof["kernel"] = dom["name"]
+    roof["avg_launch_us"] = dom["avg_us"]
+    roof["launches_per_step"] = dom["launches"] / max(1, steps_profiled)
+    step_us = sum(p["per_step_us"] for p in prof)
+    kernels = [{"name": p["name"], "launches_per_step": p["launches"] / steps_profiled, "avg_us": round(p["avg_us"], 2),
+                "share": round(p["per_step_us"] / step_us, 4),
+                "TFLOP/s": round(p["flops"] / (p["total_ms"] / 1e3) / 1e12, 2) if p["flops"] else None,
+                "GB/s": round(p["bytes"] / (p["total_ms"] / 1e3) / 1e9, 1)}
+               for p in sorted(prof, key=lambda p: -p["total_ms"])[:12]]
+    return roof, kernels
+
+
+class Runner:
+    """One workload on this rank's GPU: model, resident frames, the serial / pipelined frame loops and a state snapshot."""
+
+    def __init__(self, wl, rank, device):
+        self.wl = wl
+        self.model, self.sd = build_model(wl, device)
+        self.video_cpu, self.pts_cpu = make_inputs(wl, rank)
+        video = self.video_cpu.to(device)                  # (B,T,3,H,W) resident in HBM
+        self.pts = self.pts_cpu.to(device)
+        self.B, self.N = self.pts.shape[:2]
+        self.nfr = wl["frames"]
+        self.model.init_streams(self.pts, video[:, 0].contiguous())
+        self.frames = [video[:, 1 + i].contiguous() for i in range(self.nfr)]
+        self.tok = None
+
+    def run(self, n, pipeline=False, first=0):
+        """n complete frames (n encoder passes, n tracker passes).  Pipelined, the encoder of frame i+1 is enqueued on a second
+        HIP stream before the per-point phase of frame i (the first frame is encoded inline, the last prefetches nothing)."""
+        m, fr, nfr = self.model, self.frames, self.nfr
+        out = None
+        for i in range(first, first + n):
+            if pipeline:
+                if i + 1 < first + n:
+                    m.prefetch(fr[(i + 1) % nfr])
+                out = m.online_forward_batch(fr[i % nfr])
+            else:
+                out = m.online_forward_batch(fr[i % nfr], tokens=self.tok)
+                self.tok = out[3]
+        if pipeline:
+            self.tok = None
+        return out
+
+    def snapshot(self):
+        m = self.model
+        return (m._stream.clone(), m._coll.clone(), m._vis.clone(), m._mem.clone(), m._head, m.t)
+
+    def restore(self, snap):
+        m = self.model
+        m._stream.copy_(snap[0]); m._coll.copy_(snap[1]); m._vis.copy_(snap[2]); m._mem.copy_(snap[3])
+        m._head, m.t = snap[4], snap[5]
+
+    def fingerprint(self, out):
+        """Everything a frame loop leaves behind: the last frame's tracks and logits, and both memories with their masks."""
+        m = self.model
+        return [out[0].clone(), m.last_logits[0].clone(), m.last_logits[1].clone(), out[1].clone(), m._stream.clone(), m._coll.clone(),
+                m._vis.clone(), m._mem.clone()]
+
+    def profile(self, nprof):
+        from lbm_amd import hip
+        self.model.use_graph = False            # the per-launch events live in the eager path, not in graph replays
+        hip.profile_begin()
+        self.run(nprof)
+        prof = hip.profile_end()
+        for p in prof:
+            p["avg_us"] = 1e3 * p["total_ms"] / max(p["launches"], 1)
+            p["per_step_us"] = 1e3 * p["total_ms"] / nprof
+        return prof
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a child torch.distributed.run (this process has not
+    touched the GPU and never will) and pass its output and exit code on."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="default: c2 at --gpus 1, c3 (64 streams per GPU = BASELINE config 4) at --gpus > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-extra-workloads", action="store_true", help="N = 1: skip the c3 / c5 entries of `workloads`")
     ap.add_argument("--pipeline", action="store_true",
-                    help="force the frame pipeline on (LBM_online.prefetch: frame t+1's encoder on a second HIP stream beside "
-                         "frame t's per-point phase); default: decided by a short probe during warm-up")
-    ap.add_argument("--no-pipeline", action="store_true", help="force strictly serial frames")
+                    help="time the frame pipeline (LBM_online.prefetch) in the HEADLINE instead of serial frames; the line then says so "
+                         "and still carries pipeline_bit_identical")
+    ap.add_argument("--no-pipeline", action="store_true", help="serial frames only: skip the secondary pipelined measurement")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
-    wl = WORKLOADS[args.workload]
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks")
+    wname = args.workload or ("c2" if world == 1 else "c3")
+    wl = WORKLOADS[wname]
     if args.single_device:
         local = 0
     torch.cuda.set_device(local)
@@ -141,12 +266,6 @@ def main():
     for kv in os.environ.get("LBM_DEBUG_SET", "").split(","):        # tuning knobs, e.g. LBM_DEBUG_SET=3:4
         if kv:
             hip.load().lbm_hip_debug_set(int(kv.split(":")[0]), int(kv.split(":")[1]))
-    model, sd = build_model(wl, device)
-    video_cpu, pts_cpu = make_inputs(wl, rank)
-    video = video_cpu.to(device)                       # (B,T,3,H,W) resident in HBM
-    pts = pts_cpu.to(device)
-    B, N = pts.shape[:2]
-    nfr = wl["frames"]
 
     def barrier():
         torch.cuda.synchronize()
@@ -154,85 +273,90 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    headline_pipelined = args.pipeline or os.environ.get("LBM_AMD_PIPELINE") == "1"
+    secondary = not args.no_pipeline and world == 1
     with torch.no_grad():
-        model.init_streams(pts, video[:, 0].contiguous())
-        frames = [video[:, 1 + i].contiguous() for i in range(nfr)]
-        tok = None
-        # Frame pipeline (LBM_online.prefetch): encoder + value/correlation maps of frame t+1 on a second HIP stream beside
-        # the per-point phase of frame t; bit-identical tracks (tests/test_hip_parity.py).  Whether two queues of one process
-        # overlap or get in each other's way differs from box to box (measured both: -11 % and +30 % step time), so unless
-        # forced (--pipeline / --no-pipeline, LBM_AMD_PIPELINE=0|1) both forms are timed on a few warm-up frames and the
-        # faster one runs the timed steps.
-        forced = os.environ.get("LBM_AMD_PIPELINE")
-        if args.pipeline:
-            forced = "1"
-        if args.no_pipeline:
-            forced = "0"
-        pipeline = forced == "1"
-
-        def run(n):
-            # n complete frames: n encoder passes and n tracker passes, all inside the caller's barriers.  Pipelined, the
-            # encoder of frame i+1 is enqueued on a second HIP stream before the per-point phase of frame i (the first
-            # frame of a run is encoded inline, the last one prefetches nothing).
-            nonlocal tok
-            out = None
-            for i in range(n):
-                if pipeline:
-                    if i + 1 < n:
-                        model.prefetch(frames[(i + 1) % nfr])
-                    out = model.online_forward_batch(frames[i % nfr])
-                else:
-                    out = model.online_forward_batch(frames[i % nfr], tokens=tok)
-                    tok = out[3]
-            return out
-
-        probe = {}
-        if forced is None:
-            run(3)
-            for mode in (False, True, False, True):
-                pipeline, tok = mode, None
-                barrier()
-                tp = time.perf_counter()
-                run(12)
-                torch.cuda.synchronize()
-                probe[mode] = min(probe.get(mode, 1e9), (time.perf_counter() - tp) / 12)
-            pipeline = probe[True] < 0.97 * probe[False]
-            if dist is not None:      # one decision for the whole job (rank 0's)
-                flag = torch.tensor([1 if pipeline else 0], device=device if args.backend == "nccl" else "cpu")
-                dist.broadcast(flag, 0)
-                pipeline = bool(flag.item())
-            tok = None
-
-        run(args.warmup)
+        r = Runner(wl, rank, device)
+        B, N = r.B, r.N
+        r.run(args.warmup, pipeline=headline_pipelined)
+        torch.cuda.synchronize()
+        snap = r.snapshot()
         barrier()
         t0 = time.perf_counter()
-        coords, vis, rho, tok = run(args.steps)
+        out = r.run(args.steps, pipeline=headline_pipelined)
         barrier()
         elapsed = time.perf_counter() - t0
-        if pipeline:
-            tok = None
+        coords, vis, rho = out[0], out[1], out[2]
+        fp_head = r.fingerprint(out)
 
-        # p50 per-frame latency: each frame synchronised on its own
+        # the other frame loop from the same starting state: timed the same way, and compared bit for bit
+        other = None
+        if secondary or headline_pipelined:
+            r.restore(snap)
+            r.run(2, pipeline=not headline_pipelined)          # (its first use allocates the second slot / warms its path)
+            r.restore(snap)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            out2 = r.run(args.steps, pipeline=not headline_pipelined)
+            torch.cuda.synchronize()
+            el2 = time.perf_counter() - t1
+            fp2 = r.fingerprint(out2)
+            same = all(torch.equal(a, b) for a, b in zip(fp_head, fp2))
+            other = {"ms_per_step": 1e3 * el2 / args.steps, "value": float(B) * N * args.steps / el2, "bit_identical": same}
+
+        # p50 per-frame latency: each (serial) frame synchronised on its own
         lat = []
         for i in range(min(args.steps, 50)):
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            model.online_forward_batch(frames[i % nfr], tokens=tok)
+            r.run(1, first=i)
             torch.cuda.synchronize()
             lat.append((time.perf_counter() - t1) * 1e3)
 
         # per-kernel HIP-event timing of the same step (separate pass so the events do not perturb `elapsed`)
-        prof = []
-        if not args.no_profile and rank == 0:
-            nprof = min(args.steps, 20)
-            model.use_graph = False            # the per-launch events live in the eager path, not in graph replays
-            hip.profile_begin()
-            for i in range(nprof):
-                model.online_forward_batch(frames[i % nfr], tokens=tok)
-            prof = hip.profile_end()
-            for p in prof:
-                p["avg_us"] = 1e3 * p["total_ms"] / max(p["launches"], 1)
-                p["per_step_us"] = 1e3 * p["total_ms"] / nprof
+        nprof = min(args.steps, 20)
+        prof = r.profile(nprof) if (not args.no_profile and rank == 0) else []
+
+        # N = 1: the throughput regime in the same line (BASELINE configs 3 and 5), fewer steps each
+        extra = {}
+        if world == 1 and not args.no_extra_workloads and args.workload is None:
+            sd_keep, vid_keep, pts_keep = r.sd, r.video_cpu, r.pts_cpu
+            del r, out, fp_head, snap
+            torch.cuda.empty_cache()
+            for name, steps in (("c3", 12), ("c5", 30)):
+                w2 = WORKLOADS[name]
+                r2 = Runner(w2, rank, device)
+                r2.run(4)
+                torch.cuda.synchronize()
+                snap2 = r2.snapshot()
+                t1 = time.perf_counter()
+                o_s = r2.run(steps)
+                torch.cuda.synchronize()
+                e_s = time.perf_counter() - t1
+                f_s = r2.fingerprint(o_s)
+                r2.restore(snap2)
+                r2.run(2, pipeline=True)
+                r2.restore(snap2)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                o_p = r2.run(steps, pipeline=True)
+                torch.cuda.synchronize()
+                e_p = time.perf_counter() - t1
+                same2 = all(torch.equal(a, b) for a, b in zip(f_s, r2.fingerprint(o_p)))
+                roof2, _ = roofline_of(r2.profile(4), 4) if not args.no_profile else (None, [])
+                fl = step_flops(w2, r2.N, r2.B)
+                extra[name] = {"workload": w2["desc"], "steps": steps, "ms_per_step": 1e3 * e_s / steps,
+                               "value": float(r2.B) * r2.N * steps / e_s, "unit": "point-frames/s",
+                               "step_algorithmic_TFLOPs": fl / (e_s / steps) / 1e12,
+                               "step_frac_of_f16_mfma_peak": fl / (e_s / steps) / 1e12 / F16_MFMA_PEAK_TF,
+                               "frame_pipeline": {"ms_per_step": 1e3 * e_p / steps, "value": float(r2.B) * r2.N * steps / e_p,
+                                                  "bit_identical": same2},
+                               "roofline": roof2}
+                del r2, o_s, o_p, f_s, snap2
+                torch.cuda.empty_cache()
+            sd, video_cpu, pts_cpu = sd_keep, vid_keep, pts_keep
+        else:
+            sd, video_cpu, pts_cpu = r.sd, r.video_cpu, r.pts_cpu
 
     # results travel over RCCL only here (gather of the last frame's tracks), as the north star asks
     from lbm_amd.sharding import gather_tracks, max_over_ranks, pack_tracks
@@ -246,53 +370,40 @@ def main():
 
     if rank == 0:
         total_pf = float(B) * N * world * args.steps
+        mode_txt = ("encoder + value/correlation maps of frame t+1 on a second HIP stream, overlapping the per-point phase of frame t"
+                    if headline_pipelined else "none in the timed region (strictly serial frames)")
         line = {
             "metric": "point-frames/sec (whole node) dense-grid tracking; p50 per-frame latency",
             "value": total_pf / elapsed, "unit": "point-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16" if os.environ.get("LBM_AMD_PRECISION", "split") == "f16" else "f32", "data": "synthetic (seeded video, seeded lbm.pt-layout weights)",
-            "config": {"workload": f"{args.workload}: {wl['desc']}", "streams_per_gpu": B, "points_per_stream": N,
-                       "memory_size": wl["M"], "frame": [wl["H"], wl["W"]],
-                       "frame_pipeline": ("encoder + value/correlation maps of frame t+1 on a second HIP stream, overlapping the "
-                                          "per-point phase of frame t" if pipeline else "none (serial frames)") +
-                                         (f"; chosen by warm-up probe: serial {1e3 * probe[False]:.3f} ms/frame, pipelined "
-                                          f"{1e3 * probe[True]:.3f} ms/frame" if probe else "; forced"),
+            "config": {"workload": f"{wname}: {wl['desc']}", "streams_per_gpu": B, "points_per_stream": N,
+                       "memory_size": wl["M"], "frame": [wl["H"], wl["W"]], "frame_pipeline": mode_txt,
                        "precision": PRECISION_LABEL[os.environ.get("LBM_AMD_PRECISION", "split")], "parallelism": f"streams x{world} (no collective in the step)"},
             "p50_latency_ms": statistics.median(lat),
+            "step_algorithmic_TFLOPs": step_flops(wl, N, B) / (elapsed / args.steps) / 1e12,
         }
-        if prof:
-            dom = max(prof, key=lambda p: p["total_ms"])
-            is_mfma = dom["name"].startswith(("gemm_", "conv_"))
-            sec = dom["total_ms"] / 1e3
-            if is_mfma:
-                ach = dom["flops"] / sec / 1e12            # ALGORITHMIC flops (2 M N K) per second
-                f32 = dom["name"].startswith(("gemm_f32", "conv_f32"))
-                peak = F32_MFMA_PEAK_TF if f32 else F16_MFMA_PEAK_TF
-                line["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                                    "frac": ach / peak, "traffic": None,
-                                    "mfma_flops_per_algorithmic_flop": 1 if (f32 or dom["name"].startswith(("gemm_sh", "conv_sh"))) else 3}
-            else:
-                ach = dom["bytes"] / sec / 1e9
-                line["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                    "frac": ach / HBM_PEAK_GBS, "traffic": None}
+        if other is not None:
+            key = "serial_frames" if headline_pipelined else "frame_pipeline"
+            line[key] = {"ms_per_step": other["ms_per_step"], "value": other["value"], "unit": "point-frames/s",
+                         "note": "same starting state, same frames, timed after the headline region; not the headline"}
+            line["pipeline_bit_identical"] = other["bit_identical"]
+        roof, kernels = roofline_of(prof, nprof)
+        if roof is not None:
             # HBM-side bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate
             # runs, gfx950 corrections applied by scripts/pmc_traffic.py); counters cannot be read from inside this process
-            pmc = sorted((pathlib.Path(__file__).parent / "profiles").glob(f"r*_{args.workload}_pmc.json"))
+            pmc = sorted((pathlib.Path(__file__).parent / "profiles").glob(f"r*_{wname}_pmc.json"))
             if pmc:
-                ent = json.loads(pmc[-1].read_text())["kernels"].get(dom["name"])
+                ent = json.loads(pmc[-1].read_text())["kernels"].get(roof["kernel"])
                 if ent:
-                    line["roofline"]["traffic"] = ent["traffic_bytes_per_launch"]
-                    line["roofline"]["traffic_source"] = f"profiles/{pmc[-1].name}"
-                    line["roofline"]["algorithmic_bytes_per_launch"] = dom["bytes"] / max(dom["launches"], 1)
-            line["roofline"]["kernel"] = dom["name"]
-            line["roofline"]["avg_launch_us"] = dom["avg_us"]
-            line["roofline"]["launches_per_step"] = dom["launches"] / max(1, min(args.steps, 20))
-            step_us = sum(p["per_step_us"] for p in prof)
-            line["kernels"] = [{"name": p["name"], "launches_per_step": p["launches"] / min(args.steps, 20),
-                                "avg_us": round(p["avg_us"], 2), "share": round(p["per_step_us"] / step_us, 4),
-                                "TFLOP/s": round(p["flops"] / (p["total_ms"] / 1e3) / 1e12, 2) if p["flops"] else None,
-                                "GB/s": round(p["bytes"] / (p["total_ms"] / 1e3) / 1e9, 1)}
-                               for p in sorted(prof, key=lambda p: -p["total_ms"])[:12]]
+                    dom = next(p for p in prof if p["name"] == roof["kernel"])
+                    roof["traffic"] = ent["traffic_bytes_per_launch"]
+                    roof["traffic_source"] = f"profiles/{pmc[-1].name}"
+                    roof["algorithmic_bytes_per_launch"] = dom["bytes"] / max(dom["launches"], 1)
+            line["roofline"] = roof
+            line["kernels"] = kernels
+        if extra:
+            line["workloads"] = extra
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(wl, sd, video_cpu, pts_cpu)
         print(json.dumps(line), flush=True)

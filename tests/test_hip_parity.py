@@ -781,32 +781,34 @@ def test_graph_replay_and_point_parallel_streams_match_the_plain_eager_step(hip,
 def test_frame_pipeline_gives_the_same_tracks_as_serial_frames(hip):
     """prefetch(frame t+1) on the encoder stream while frame t's per-point phase runs: same kernels on the same data,
     so coordinates, logits and the ring state must be bit-identical to the serial loop (15 frames, ring wraps, the
-    two token / workspace slots are each reused 7 times)."""
+    two token / workspace slots are each reused 7 times).  Six pipelined runs against one serial run: the screen of
+    DESIGN.md section 8 (scripts/pipe_screen.py) as a test."""
     from lbm_amd.synth import synthetic_video, grid_queries
     T, H, W = 16, 240, 320
     video = synthetic_video(T, H, W, seed=21).cuda()
     frames = [video[:, t].contiguous() for t in range(T)]
     pts = grid_queries(H, W, 32).cuda()
     runs = {}
-    for mode in ("serial", "pipelined"):
+    for mode in ("serial", "pipelined", "pipelined2", "pipelined3", "pipelined4", "pipelined5", "pipelined6"):
         model, _ = _online(dict(input_size=(384, 512), memory_size=12))
         out = []
         with torch.no_grad():
             model.init(pts, frames[0])
             for t in range(1, T):
-                if mode == "pipelined" and t + 1 < T:
+                if mode != "serial" and t + 1 < T:
                     model.prefetch(frames[t + 1])
                 c, v, r, f_t = model.online_forward(frames[t])
                 out.append((c.clone(), model.last_logits[0][0].clone(), r.clone(), f_t.clone()))
         torch.cuda.synchronize()
-        if mode == "pipelined":
+        if mode != "serial":
             assert model.pipelined_frames == T - 2 and not model._pf      # all but the first tracked frame ran ahead
         runs[mode] = (out, model.stream_dist.clone(), model.collision_dist.clone(), model.vis_mask.clone())
-    for a, b in zip(runs["serial"][0], runs["pipelined"][0]):
-        for x, y in zip(a, b):
-            assert torch.equal(x, y)
-    for i in (1, 2, 3):
-        assert torch.equal(runs["serial"][i], runs["pipelined"][i])
+    for mode in runs:
+        for a, b in zip(runs["serial"][0], runs[mode][0]):
+            for x, y in zip(a, b):
+                assert torch.equal(x, y), mode
+        for i in (1, 2, 3):
+            assert torch.equal(runs["serial"][i], runs[mode][i]), mode
 
 
 def test_correlation_product_with_fused_top_k_selects_the_same_cells(hip):

@@ -128,6 +128,13 @@ int lbm_hip_msda_sample(const lbm_hip_msda_desc* d, lbm_stream_t stream);
 int lbm_hip_preprocess(const float* frames, int64_t frame_bstride, float* out, int32_t B, int32_t H, int32_t W,
                        int32_t oh, int32_t ow, int32_t out_nhwc /* 0: [B,3,oh,ow]; 3 or 4: [B,oh,ow,c], channel 3 zero */,
                        lbm_stream_t stream);
+/* Video ingest: the same pre-processing straight from the decoder's bytes, so frames cross PCIe and HBM as uint8 (a quarter
+ * of the bytes of demo_utils.py:127-131's float tensor) and the BGR->RGB / HWC->CHW / float conversions of the host loader
+ * (demo_utils.py:127-131) happen in the kernel.  in_layout 0: planar (B,3,H,W) RGB; 1: interleaved (B,H,W,3) RGB;
+ * 2: interleaved (B,H,W,3) BGR (OpenCV's order).  frame_bstride in bytes (= elements).  Bit-identical to lbm_hip_preprocess on
+ * the same pixel values.                                                                                                   */
+int lbm_hip_preprocess_u8(const uint8_t* frames, int64_t frame_bstride, int32_t in_layout, float* out, int32_t B, int32_t H, int32_t W,
+                          int32_t oh, int32_t ow, int32_t out_nhwc, lbm_stream_t stream);
 int lbm_hip_upcat(const float* p1, const float* p2, const float* p3, float* out, int32_t B, int32_t h, int32_t w,
                   lbm_stream_t stream);
 int lbm_hip_sample_queries(const float* tokens, int64_t tok_bstride, int32_t ld, const float* pts, float* out,

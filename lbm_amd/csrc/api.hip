@@ -613,6 +613,11 @@ int lbm_hip_preprocess(const float* frames, int64_t frame_bstride, float* out, i
   return preprocess(frames, frame_bstride, out, B, H, W, oh, ow, out_nhwc, (hipStream_t)stream);
 }
 
+int lbm_hip_preprocess_u8(const uint8_t* frames, int64_t frame_bstride, int32_t in_layout, float* out, int32_t B, int32_t H, int32_t W,
+                          int32_t oh, int32_t ow, int32_t out_nhwc, lbm_stream_t stream) {
+  return preprocess_u8(frames, frame_bstride, in_layout, out, B, H, W, oh, ow, out_nhwc, (hipStream_t)stream);
+}
+
 int lbm_hip_upcat(const float* p1, const float* p2, const float* p3, float* out, int32_t B, int32_t h, int32_t w,
                   lbm_stream_t stream) {
   return upcat(p1, p2, p3, out, B, h, w, (hipStream_t)stream);

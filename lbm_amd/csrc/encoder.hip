@@ -14,8 +14,13 @@ __device__ __forceinline__ void resize_coeff(int dst, float scale, int in, int& 
   l0 = 1.0f - l1;
 }
 
-// backbone.py:181-183: x/255 -> bilinear resize (no antialias) -> (x - mean)/std.   NCHW in, NCHW out.
-__global__ __launch_bounds__(256) void preprocess_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H,
+// backbone.py:181-183: x/255 -> bilinear resize (no antialias) -> (x - mean)/std.   NCHW or NHWC out.
+// T = float: frames as the reference hands them over, (B,3,H,W) fp32 in [0,255] (tools/demo_grid.py:40).
+// T = uint8_t: the decoder's own bytes (demo_utils.py:127-131 converts them to float on the host, 4x the bytes over PCIe and
+//   out of HBM): LAYOUT 0 planar (B,3,H,W) RGB; 1 interleaved (B,H,W,3) RGB; 2 interleaved (B,H,W,3) BGR (cv2's order).
+//   uint8 -> float is exact, so the result is bit-identical to the fp32 path on the same values.
+template <typename T, int LAYOUT>
+__global__ __launch_bounds__(256) void preprocess_kernel(const T* __restrict__ in, float* __restrict__ out, int B, int H,
                                                          int W, int oh, int ow, long long in_bstride, int out_nhwc) {
   const float sy = (float)H / (float)oh, sx = (float)W / (float)ow;
   const long long total = (long long)B * 3 * oh * ow;
@@ -28,9 +33,13 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const float* __restrict
     float ly0, ly1, lx0, lx1;
     resize_coeff(y, sy, H, y0, y1, ly0, ly1);
     resize_coeff(x, sx, W, x0, x1, lx0, lx1);
-    const float* p = in + (long long)b * in_bstride + (long long)c * H * W;
-    const float v00 = p[(long long)y0 * W + x0] / 255.0f, v01 = p[(long long)y0 * W + x1] / 255.0f;
-    const float v10 = p[(long long)y1 * W + x0] / 255.0f, v11 = p[(long long)y1 * W + x1] / 255.0f;
+    const T* p = in + (long long)b * in_bstride;
+    auto px = [&](int yy, int xx) {
+      if constexpr (LAYOUT == 0) return (float)p[(long long)c * H * W + (long long)yy * W + xx];
+      else return (float)p[((long long)yy * W + xx) * 3 + (LAYOUT == 2 ? 2 - c : c)];
+    };
+    const float v00 = px(y0, x0) / 255.0f, v01 = px(y0, x1) / 255.0f;
+    const float v10 = px(y1, x0) / 255.0f, v11 = px(y1, x1) / 255.0f;
     const float v = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
     const float mean = c == 0 ? 0.485f : (c == 1 ? 0.456f : 0.406f);
     const float sd = c == 0 ? 0.229f : (c == 1 ? 0.224f : 0.225f);
@@ -41,15 +50,34 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const float* __restrict
   }
 }
 
-int preprocess(const float* frames, long long frame_bstride, float* out, int B, int H, int W, int oh, int ow, int out_nhwc,
-               hipStream_t stream) {
+static int preprocess_check(const void* frames, float* out, int B, int H, int W, int oh, int ow, int out_nhwc, long long& blocks) {
   LBM_REQUIRE(frames && out && B > 0 && H > 0 && W > 0 && oh > 0 && ow > 0, "preprocess: bad arguments");
   LBM_REQUIRE(out_nhwc == 0 || out_nhwc == 3 || out_nhwc == 4, "preprocess: out_nhwc must be 0, 3 or 4");
-  long long blocks = ((long long)B * 3 * oh * ow + 255) / 256;
+  blocks = ((long long)B * 3 * oh * ow + 255) / 256;
   if (blocks > 65535) blocks = 65535;
+  return 0;
+}
+
+int preprocess(const float* frames, long long frame_bstride, float* out, int B, int H, int W, int oh, int ow, int out_nhwc,
+               hipStream_t stream) {
+  long long blocks;
+  if (preprocess_check(frames, out, B, H, W, oh, ow, out_nhwc, blocks)) return -1;
   ProfScope prof("preprocess", stream, 0.0, 4.0 * B * 3 * ((double)H * W + (double)oh * ow));
-  hipLaunchKernelGGL(preprocess_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, frames, out, B, H, W, oh, ow, frame_bstride, out_nhwc);
+  hipLaunchKernelGGL((preprocess_kernel<float, 0>), dim3((unsigned)blocks), dim3(256), 0, stream, frames, out, B, H, W, oh, ow, frame_bstride, out_nhwc);
   return check_launch("preprocess");
+}
+
+int preprocess_u8(const uint8_t* frames, long long frame_bstride, int in_layout, float* out, int B, int H, int W, int oh, int ow,
+                  int out_nhwc, hipStream_t stream) {
+  long long blocks;
+  if (preprocess_check(frames, out, B, H, W, oh, ow, out_nhwc, blocks)) return -1;
+  LBM_REQUIRE(in_layout >= 0 && in_layout <= 2, "preprocess_u8: in_layout must be 0 (planar RGB), 1 (interleaved RGB) or 2 (interleaved BGR)");
+  ProfScope prof("preprocess_u8", stream, 0.0, (double)B * 3 * ((double)H * W + 4.0 * oh * ow));
+  const dim3 grid((unsigned)blocks), blk(256);
+  if (in_layout == 0) hipLaunchKernelGGL((preprocess_kernel<uint8_t, 0>), grid, blk, 0, stream, frames, out, B, H, W, oh, ow, frame_bstride, out_nhwc);
+  else if (in_layout == 1) hipLaunchKernelGGL((preprocess_kernel<uint8_t, 1>), grid, blk, 0, stream, frames, out, B, H, W, oh, ow, frame_bstride, out_nhwc);
+  else hipLaunchKernelGGL((preprocess_kernel<uint8_t, 2>), grid, blk, 0, stream, frames, out, B, H, W, oh, ow, frame_bstride, out_nhwc);
+  return check_launch("preprocess_u8");
 }
 
 // backbone.py:57-62: cat([p1, up2(p2), up4(p3)]) with pixel-major (NHWC) 64-channel maps -> [B*h*w, 192].

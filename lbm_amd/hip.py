@@ -28,7 +28,7 @@ EXPORTS = (
     "lbm_hip_profile_begin", "lbm_hip_profile_end", "lbm_hip_split_planes", "lbm_hip_debug_set", "lbm_hip_linear_ss",
     "lbm_hip_conv2d_nhwc_ss", "lbm_hip_maxpool3x3s2_nhwc_s", "lbm_hip_upcat_s", "lbm_hip_pyramid_s",
     "lbm_hip_update_points", "lbm_hip_encoder_tail", "lbm_hip_pack_fragment_major", "lbm_hip_ffn_slabs",
-    "lbm_hip_debug_ptr", "lbm_hip_update_points_static",
+    "lbm_hip_debug_ptr", "lbm_hip_update_points_static", "lbm_hip_preprocess_u8",
 )
 
 
@@ -138,6 +138,7 @@ def load() -> C.CDLL:
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.lbm_hip_msda_sample.argtypes = [C.POINTER(MsdaDesc), C.c_void_p]
     lib.lbm_hip_preprocess.argtypes = [C.c_void_p, C.c_int64, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p]
+    lib.lbm_hip_preprocess_u8.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p]
     lib.lbm_hip_upcat.argtypes = [C.c_void_p] * 4 + [C.c_int32] * 3 + [C.c_void_p]
     lib.lbm_hip_sample_queries.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p]
     lib.lbm_hip_pack_fragment_major.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
@@ -565,17 +566,36 @@ def msda_forward(mod, query, value, reference_points, shapes, identity) -> torch
     return out.view(B, Q, 256)
 
 
-def preprocess(frames: torch.Tensor, oh: int, ow: int, layout: int = 0) -> torch.Tensor:
+U8_LAYOUTS = {"chw": 0, "hwc_rgb": 1, "hwc_bgr": 2}
+
+
+def preprocess(frames: torch.Tensor, oh: int, ow: int, layout: int = 0, u8_layout: str = "chw") -> torch.Tensor:
     """frames (B,3,H,W) fp32 in [0,255] -> normalised image.  layout 0: (B,3,oh,ow); 3 / 4: pixel-major
-    (B,oh,ow,layout) with channel 3 zero-filled (what the NHWC convolution stem reads)."""
+    (B,oh,ow,layout) with channel 3 zero-filled (what the NHWC convolution stem reads).
+    uint8 frames are read as they are (lbm_hip_preprocess_u8): (B,3,H,W) for u8_layout "chw", (B,H,W,3) for "hwc_rgb" /
+    "hwc_bgr" (a decoder's interleaved output; BGR = OpenCV's order)."""
     _require_gpu()
-    B, Cc, H, W = frames.shape
-    assert Cc == 3 and layout in (0, 3, 4)
-    frames = frames.float().contiguous()
+    assert layout in (0, 3, 4)
+    if frames.dtype == torch.uint8:
+        code = U8_LAYOUTS[u8_layout]
+        frames = frames.contiguous()
+        if code == 0:
+            B, Cc, H, W = frames.shape
+        else:
+            B, H, W, Cc = frames.shape
+        assert Cc == 3
+    else:
+        B, Cc, H, W = frames.shape
+        assert Cc == 3
+        frames = frames.float().contiguous()
     shape = (B, 3, oh, ow) if layout == 0 else (B, oh, ow, layout)
     out = torch.empty(shape, device=frames.device, dtype=torch.float32)
-    _check(load().lbm_hip_preprocess(frames.data_ptr(), 3 * H * W, out.data_ptr(), B, H, W, oh, ow, layout, _stream()),
-           "lbm_hip_preprocess")
+    if frames.dtype == torch.uint8:
+        _check(load().lbm_hip_preprocess_u8(frames.data_ptr(), 3 * H * W, code, out.data_ptr(), B, H, W, oh, ow, layout, _stream()),
+               "lbm_hip_preprocess_u8")
+    else:
+        _check(load().lbm_hip_preprocess(frames.data_ptr(), 3 * H * W, out.data_ptr(), B, H, W, oh, ow, layout, _stream()),
+               "lbm_hip_preprocess")
     return out
 
 

@@ -100,3 +100,77 @@ def test_online_init_update_forward(gold):
     assert (o.mem_mask[0].cpu().numpy() == g["on_mem_mask_final"]).all()
     assert (o.vis_mask[0].cpu().numpy() == g["on_vis_mask_final"]).mean() > 0.99
     assert o.t == int(g["on_t"])
+
+
+def test_uint8_frames_track_bit_identically_to_float_frames(gold):
+    """Video ingest: frames handed over as the decoder's uint8 bytes -- planar through the model API,
+    interleaved RGB / BGR at the operator -- give exactly the bits of the reference-style float frames (demo_utils.py:127-131)."""
+    from lbm_amd import hip
+    _, inp = gold
+    video = inp["video"].cuda()                                   # integer-valued floats in [0, 255]
+    v8 = video.to(torch.uint8)
+    assert torch.equal(v8.float(), video)
+    want = hip.preprocess(video[0, :2], SIZE[0], SIZE[1], layout=4)
+    assert torch.equal(hip.preprocess(v8[0, :2], SIZE[0], SIZE[1], layout=4), want)
+    hwc = v8[0, :2].permute(0, 2, 3, 1).contiguous()
+    assert torch.equal(hip.preprocess(hwc, SIZE[0], SIZE[1], layout=4, u8_layout="hwc_rgb"), want)
+    assert torch.equal(hip.preprocess(hwc.flip(-1).contiguous(), SIZE[0], SIZE[1], layout=4, u8_layout="hwc_bgr"), want)
+    assert torch.equal(hip.preprocess(v8[0, :2], SIZE[0], SIZE[1], layout=0), hip.preprocess(video[0, :2], SIZE[0], SIZE[1], layout=0))
+    a, b = _model("LBM_online"), _model("LBM_online")
+    with torch.no_grad():
+        a.init(inp["pts0"].cuda(), video[:, 0])
+        b.init(inp["pts0"].cuda(), v8[:, 0])
+        for t in range(1, 5):
+            ca, va, ra, _ = a.online_forward(video[:, t])
+            cb, vb, rb, _ = b.online_forward(v8[:, t])
+            assert torch.equal(ca, cb) and torch.equal(va, vb) and torch.equal(ra, rb)
+
+
+@pytest.mark.parametrize("M", [20, 36, 48, 60])
+def test_inference_at_the_eval_memory_sizes_against_the_oracle(M):
+    """LBM.inference at the memory sizes of lbm/configs/lbm.yaml:41-52 (SURVEY section 8 f3): M + 6 frames, so the ring wraps;
+    queries start at frames 0..3; every frame against the oracle (tie rule of tests/test_hip_configs.py)."""
+    from oracle import lbm_ref_cpu as ref
+    from lbm_amd.synth import synthetic_state_dict, synthetic_video
+    m = _model("LBM")
+    g = ref.Geometry(size=SIZE, memory_size=12)
+    sd = {k: v.clone() for k, v in synthetic_state_dict(m, seed=42).items()}
+    m.set_memory_size(M)
+    ref.resize_time_embeddings(sd, g, M)
+    T, (H, W), N = M + 6, FRAME, 24
+    video = synthetic_video(T, H, W, seed=50 + M)
+    r = np.random.default_rng(M)
+    q = np.stack([r.integers(0, 4, N), r.uniform(8, W - 8, N), r.uniform(8, H - 8, N)], -1).astype(np.float32)
+    queries = torch.from_numpy(q).unsqueeze(0)
+    m.extend_queries = False
+    with torch.no_grad():
+        got = m.inference(video.cuda(), queries.clone().cuda())
+        # the oracle's loop (oracle/lbm_ref_cpu.py: inference) with the gaps of its own selections on the side
+        qs = queries.clone()
+        qs[:, :, 2] = qs[:, :, 2] / H * SIZE[0]
+        qs[:, :, 1] = qs[:, :, 1] / W * SIZE[1]
+        times = qs[:, :, 0].long()
+        feats = [ref.encode_frames(sd, g, video[:, t]) for t in range(T)]
+        q_init = torch.zeros(1, N, 256)
+        for t in range(4):
+            sel = times[0] == t
+            if bool(sel.any()):
+                q_init[0, sel] = ref.sample_queries(feats[t], qs[0, sel, 1:], g)
+        st = ref.fresh_state(q_init, g)
+        tie_seen = torch.zeros(N, dtype=torch.bool)
+        dropped = torch.zeros(N, dtype=torch.bool)
+        for t in range(T):
+            coords, vis, _, out = ref.track_step(sd, g, st, feats[t], times <= t)
+            for layer, k in zip(out, g.topk_per_layer):
+                tv = torch.topk(layer["corr"][0], k + 1, dim=-1)[0]
+                tie_seen |= (tv[:, k - 1] - tv[:, k]) < 1e-4
+            c = coords[0].clone()
+            c[:, 0] = c[:, 0] / SIZE[1] * W
+            c[:, 1] = c[:, 1] / SIZE[0] * H
+            live = times[0] <= t                       # before its query frame a point's output is not meaningful
+            off = ((got["points"][0, t].cpu() - c).abs().amax(-1) >= 0.05) & live
+            assert not bool((off & ~tie_seen & ~dropped).any()), f"M {M} frame {t}: tracks differ with no tie in the oracle's selection"
+            dropped |= off
+            flag_ok = ((torch.sigmoid(vis[0]) - 0.8).abs() > 2e-3) & live & ~dropped
+            assert (got["visibility"][0, t].cpu() == (torch.sigmoid(vis[0]) > 0.8))[flag_ok].all()
+        assert dropped.float().mean() <= 0.15, f"M {M}: {int(dropped.sum())} of {N} points lost to ties"

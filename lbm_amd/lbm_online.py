@@ -170,7 +170,8 @@ class LBM_online(LBM):
     # ---- frame pipeline ------------------------------------------------------------------------
     @staticmethod
     def _frame_key(frames: torch.Tensor):
-        return (frames.data_ptr(), tuple(frames.shape), tuple(frames.stride()), frames.dtype)
+        # address, geometry and the tensor's version counter: an in-place write to the frame after prefetch() changes the key
+        return (frames.data_ptr(), tuple(frames.shape), tuple(frames.stride()), frames.dtype, frames._version)
 
     @torch.no_grad()
     def prefetch(self, frames: torch.Tensor) -> None:
@@ -221,10 +222,19 @@ class LBM_online(LBM):
 
     @torch.no_grad()
     def online_forward_batch(self, frames: torch.Tensor, tokens: Optional[torch.Tensor] = None):
-        """frames (B,3,H,W) -> coords (B,N,2) frame px, vis (B,N) bool, rho (B,N) in (0,1), tokens (B,L,C)."""
+        """frames (B,3,H,W) -> coords (B,N,2) frame px, vis (B,N) bool, rho (B,N) in (0,1), tokens (B,L,C).
+
+        Lifetime of the returned tokens: for a frame that was encoded ahead (prefetch) they are a VIEW of one of the two
+        pipeline slots and are overwritten by the prefetch after next; a caller that keeps them longer (e.g. for a later
+        update()) passes ``tokens=`` and gets a copy there -- the reference returns a fresh tensor every frame
+        (lbm_online.py:125-126).  Unpipelined frames return a fresh tensor (or ``tokens`` itself)."""
         H, W = frames.shape[-2], frames.shape[-1]
         if self._pf:
             slot = self._pf.pop(self._frame_key(frames), None)
+            if slot is None and len(self._pf) > 1:
+                # frames encoded ahead and never asked for: only the most recent prefetch can still be the next frame
+                last = next(reversed(self._pf))
+                self._pf = {last: self._pf[last]}
             p = self._pipe
             if slot is not None and p is not None and p["key"] == (frames.shape[0], self.N, self.memory_size, frames.device):
                 self.pipelined_frames += 1
@@ -262,7 +272,7 @@ class LBM_online(LBM):
 
     def _forward_graph(self, frames: torch.Tensor):
         """Replay (capturing on first use) the HIP graph of this frame step; None = not available, run eagerly."""
-        key = (tuple(frames.shape), self.N, self.memory_size, self._stream.data_ptr(), self.query.data_ptr(),
+        key = (tuple(frames.shape), self.N, self.memory_size, self._stream.data_ptr(), self.query.data_ptr(), self.query._version,
                float(self.visibility_treshold), self.transformer.precision, self.backbone.precision)
         if self._gkey != key:
             self._graphs, self._gkey, self._eager_done = {}, key, False
@@ -288,14 +298,18 @@ class LBM_online(LBM):
                                                              ring_head=head, queried=None, update_state=True, img_hw=(H, W),
                                                              vis_threshold=self.visibility_treshold,
                                                              tokens_split=self.backbone.last_tokens_split)
-                self._graphs[head] = (g, out)
+                self._graphs[head] = (g, out, self.transformer.get_engine()._qc)    # the cache entry keeps u0 / the split twin alive
             except Exception as e:          # capture not possible here: say so once and stay eager
                 import warnings
                 warnings.warn(f"lbm_amd: HIP graph capture failed ({e}); running eagerly")
                 self.use_graph = False
                 torch.cuda.synchronize()
                 return None
-        g, out = self._graphs[head]
+        g, out, qc = self._graphs[head]
+        if qc is not self.transformer.get_engine()._qc:
+            # another step replaced the engine's per-query cache (its tensors are baked into the captured graphs): start over
+            self._graphs, self._eager_done = {}, False
+            return None
         g.replay()
         self._head = (self._head + 1) % self.memory_size
         self.t += 1

@@ -10,9 +10,10 @@ for every stream the rank owns; frames are resident in HBM before the timed regi
   c3 (default at N > 1: BASELINE config 4 = 64 streams per GPU):     64 streams x 256 points, 480x854, batched in one step
   c5:  1 stream, 1080x1920, dense 100x100 grid = 10 000 points, memory M = 48
 
-The timed region runs strictly SERIAL frames.  The frame pipeline (LBM_online.prefetch: encoder of frame t+1 on a second
-HIP stream) is timed afterwards from the same starting state and reported beside the headline (``frame_pipeline``) with
-``pipeline_bit_identical``: its final tracks and memories compared bit for bit with the serial run's.
+Two frame loops are timed on the same K frames from the same state: strictly serial frames, and the frame pipeline
+(LBM_online.prefetch: encoder of frame t+1 on a second HIP stream).  ``value`` is the pipelined figure only when its final
+tracks, logits and memories are bit-identical to the serial loop's in this very run (``pipeline_bit_identical``, DESIGN.md
+section 8) and it is faster; otherwise the serial figure.  Both are in the line (``serial_frames``, ``frame_pipeline``).
 At N = 1 the line also carries ``workloads``: the throughput regime (c3, c5) measured in the same process.
 
 N > 1: ``python bench.py --gpus N`` starts N ranks itself (child ``torch.distributed.run`` before anything touches the
@@ -231,10 +232,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-extra-workloads", action="store_true", help="N = 1: skip the c3 / c5 entries of `workloads`")
-    ap.add_argument("--pipeline", action="store_true",
-                    help="time the frame pipeline (LBM_online.prefetch) in the HEADLINE instead of serial frames; the line then says so "
-                         "and still carries pipeline_bit_identical")
-    ap.add_argument("--no-pipeline", action="store_true", help="serial frames only: skip the secondary pipelined measurement")
+    ap.add_argument("--pipeline", action="store_true", help="(default behaviour; kept for compatibility)")
+    ap.add_argument("--no-pipeline", action="store_true", help="serial frames only: the frame pipeline is neither timed nor used")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -273,36 +272,41 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    headline_pipelined = args.pipeline or os.environ.get("LBM_AMD_PIPELINE") == "1"
-    secondary = not args.no_pipeline and world == 1
+    # Both frame loops are timed on the same K frames from the same starting state, each bracketed by barrier + synchronize.
+    # The headline is the frame pipeline ONLY IF its final tracks, logits and memories are bit-identical to the serial run's on
+    # every rank (pipeline_bit_identical); otherwise -- or with --no-pipeline -- it is the serial figure.  --pipeline forces
+    # nothing past that check either.
+    want_pipeline = not args.no_pipeline and os.environ.get("LBM_AMD_PIPELINE") != "0"
     with torch.no_grad():
         r = Runner(wl, rank, device)
         B, N = r.B, r.N
-        r.run(args.warmup, pipeline=headline_pipelined)
+        r.run(args.warmup)
         torch.cuda.synchronize()
         snap = r.snapshot()
         barrier()
         t0 = time.perf_counter()
-        out = r.run(args.steps, pipeline=headline_pipelined)
+        out = r.run(args.steps)
         barrier()
-        elapsed = time.perf_counter() - t0
+        el_serial = time.perf_counter() - t0
         coords, vis, rho = out[0], out[1], out[2]
-        fp_head = r.fingerprint(out)
-
-        # the other frame loop from the same starting state: timed the same way, and compared bit for bit
-        other = None
-        if secondary or headline_pipelined:
+        fp_serial = r.fingerprint(out)
+        el_pipe, same = None, False
+        if want_pipeline:
             r.restore(snap)
-            r.run(2, pipeline=not headline_pipelined)          # (its first use allocates the second slot / warms its path)
+            r.run(2, pipeline=True)                            # (its first use allocates the second slot)
             r.restore(snap)
-            torch.cuda.synchronize()
+            barrier()
             t1 = time.perf_counter()
-            out2 = r.run(args.steps, pipeline=not headline_pipelined)
-            torch.cuda.synchronize()
-            el2 = time.perf_counter() - t1
-            fp2 = r.fingerprint(out2)
-            same = all(torch.equal(a, b) for a, b in zip(fp_head, fp2))
-            other = {"ms_per_step": 1e3 * el2 / args.steps, "value": float(B) * N * args.steps / el2, "bit_identical": same}
+            out2 = r.run(args.steps, pipeline=True)
+            barrier()
+            el_pipe = time.perf_counter() - t1
+            same = all(torch.equal(a, b) for a, b in zip(fp_serial, r.fingerprint(out2)))
+            del out2
+        if dist is not None and want_pipeline:                 # one verdict for the whole job: identical on EVERY rank
+            flag = torch.tensor([1 if same else 0], device=device if args.backend == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            same = bool(flag.item())
+        del fp_serial
 
         # p50 per-frame latency: each (serial) frame synchronised on its own
         lat = []
@@ -321,7 +325,7 @@ def main():
         extra = {}
         if world == 1 and not args.no_extra_workloads and args.workload is None:
             sd_keep, vid_keep, pts_keep = r.sd, r.video_cpu, r.pts_cpu
-            del r, out, fp_head, snap
+            del r, out, snap
             torch.cuda.empty_cache()
             for name, steps in (("c3", 12), ("c5", 30)):
                 w2 = WORKLOADS[name]
@@ -366,12 +370,19 @@ def main():
     gathered = gather_tracks(res, B * world, dst=0)
     if rank == 0:
         assert gathered.shape == (B * world, N, 4) and bool(torch.isfinite(gathered).all())
-    elapsed = max_over_ranks(elapsed, device if args.backend == "nccl" else torch.device("cpu"))
+    cdev = device if args.backend == "nccl" else torch.device("cpu")
+    el_serial = max_over_ranks(el_serial, cdev)
+    if el_pipe is not None:
+        el_pipe = max_over_ranks(el_pipe, cdev)
+    headline_pipelined = el_pipe is not None and same and el_pipe < el_serial
+    elapsed = el_pipe if headline_pipelined else el_serial
 
     if rank == 0:
         total_pf = float(B) * N * world * args.steps
-        mode_txt = ("encoder + value/correlation maps of frame t+1 on a second HIP stream, overlapping the per-point phase of frame t"
-                    if headline_pipelined else "none in the timed region (strictly serial frames)")
+        mode_txt = ("encoder + value/correlation maps of frame t+1 on a second HIP stream, overlapping the per-point phase of frame t; "
+                    "verified bit-identical to the serial frame loop on these frames in this run" if headline_pipelined else
+                    "none in the headline (strictly serial frames)" + ("" if el_pipe is None else
+                                                                      ": the pipelined loop was " + ("not bit-identical" if not same else "not faster")))
         line = {
             "metric": "point-frames/sec (whole node) dense-grid tracking; p50 per-frame latency",
             "value": total_pf / elapsed, "unit": "point-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -383,11 +394,12 @@ def main():
             "p50_latency_ms": statistics.median(lat),
             "step_algorithmic_TFLOPs": step_flops(wl, N, B) / (elapsed / args.steps) / 1e12,
         }
-        if other is not None:
-            key = "serial_frames" if headline_pipelined else "frame_pipeline"
-            line[key] = {"ms_per_step": other["ms_per_step"], "value": other["value"], "unit": "point-frames/s",
-                         "note": "same starting state, same frames, timed after the headline region; not the headline"}
-            line["pipeline_bit_identical"] = other["bit_identical"]
+        per = lambda el: {"ms_per_step": 1e3 * el / args.steps, "value": total_pf / el, "unit": "point-frames/s"}
+        line["serial_frames"] = per(el_serial)
+        if el_pipe is not None:
+            line["frame_pipeline"] = per(el_pipe)
+            line["pipeline_bit_identical"] = same
+        line["headline_mode"] = "frame_pipeline" if headline_pipelined else "serial_frames"
         roof, kernels = roofline_of(prof, nprof)
         if roof is not None:
             # HBM-side bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate

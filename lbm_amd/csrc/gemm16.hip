@@ -406,6 +406,7 @@ struct GemmSSDev {
   float* cand_v;   // TOPK epilogue: per-tile candidates [batch * M, ntile_n * topk_k] (values / global columns)
   int* cand_i;
   int topk_k;
+  int xcd_remap;   // 1: XCD-contiguous tile order (grid of a multiple of 8 workgroups per z)
   int vec_ok;      // outputs / residual admit 16-byte row pieces (N, leading dimensions, strides multiples of 4; aligned bases)
 };
 
@@ -512,7 +513,17 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_ss_kernel(GemmSSDev a) {
   const int wm = wave / WN, wn = wave % WN;
   const int r = lane & 31, h = lane >> 5;
   const int z = blockIdx.z;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (a.xcd_remap) {
+    // Workgroups are dealt round-robin over the 8 XCDs (id % 8 names the XCD); give every XCD one CONTIGUOUS run of the
+    // tile sequence (column index fastest), so the row panels it touches are fetched into ONE L2 instead of all eight.
+    const int gx = gridDim.x, total = gx * gridDim.y;
+    const int id = by * gx + bx;
+    const int t = (id & 7) * (total >> 3) + (id >> 3);
+    by = t / gx;
+    bx = t - by * gx;
+  }
+  const int m0 = by * BM, n0 = bx * BN;
   if (a.dbg & 8) return;                                       // ablation: launch skeleton only
 
   // ---- DMA source addresses: piece p covers 16 rows of one plane; lane -> (row = lane / 4, slot = lane % 4) ----
@@ -733,7 +744,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_ss_kernel(GemmSSDev a) {
         }
       }
       const long long ntile = (a.N + BN - 1) / BN;
-      const long long co = ((long long)z * a.M + row) * ntile * kk + (long long)blockIdx.x * kk;
+      const long long co = ((long long)z * a.M + row) * ntile * kk + (long long)bx * kk;
       for (int t = 0; t < kk; ++t) {
         float bv = lv[0];
         int bi = li[0];
@@ -829,6 +840,12 @@ static int launch_ss(const GemmSSDev& d, int batch, hipStream_t stream) {
                          (d.Y ? " f32" : "") + (d.Ys ? " split" : "");
   GemmSSDev dv = d;
   dv.vec_ok = vec_ok_of(d);
+  // XCD-contiguous tile order where it pays: many tiles, and a B operand small enough (<= 2 MB of split planes) to sit in every
+  // XCD's L2 while the row panels of A stream through ONE L2 each instead of all eight (measured 3-8 % on 16384..1044480-row
+  // products, scripts/gemm_big.py).  A wide B (the 12288-column correlation product) would thrash instead: dispatch order
+  // keeps one column stripe per XCD there.  Debug flag 32 switches it off.
+  dv.xcd_remap = !(g_dbg16 & 32) && !CONV && ((long long)grid.x * grid.y) % 8 == 0 && (long long)grid.x * grid.y >= 512 &&
+                 (long long)d.N * d.K * 4 <= (2ll << 20) ? 1 : 0;
   ProfScope prof(by_shape ? interned.insert(shaped).first->c_str() : name.c_str(), stream, 2.0 * mnk,
                  4.0 * ((double)d.M * d.K * batch + (double)d.N * d.K * (d.sB || batch == 1 ? batch : 1) +
                         (double)d.M * d.N * batch * ((d.Y ? 1 : 0) + (d.Ys ? 1 : 0) + (d.res ? 1 : 0))));

@@ -148,6 +148,8 @@ static int build_layout(const lbm_hip_step_desc* d, StepLayout& lay) {
 }
 
 // A tensor view used by the step: fp32 rows and/or the same values as split f16 planes (hi at `s`, lo at s + plane).
+static int g_rs_topk = 1;           // tuning (debug key 13): 0 = the correlation product never takes the row-streaming kernel with per-point lists
+static int g_rs_dbg = 0;            // tuning (debug key 14): ablation bits handed to gemm_rs_topk
 static int g_fuse_kmax_small = 1;   // tuning (debug key 6): largest k fused into the correlation product at < 4096 rows
 static int g_ffn_sites = 63;        // tuning (debug key 8): 1 attention blocks, 2 lattice blocks, 4 head blocks may fuse
 static int g_ffn_fused_rows = 2048; // tuning (debug key 7): most rows for which the feed-forward runs as one fused launch (0: never)
@@ -435,11 +437,23 @@ struct Step {
         // (in the space the map would have taken) and select among those -- the R x P0 map is neither written nor re-read
         // (measured: the 9-deep per-lane lists cost the tile epilogue ~25 us at 1024 rows, more than the map's round trip
         // saves there; from ~4000 rows on the product is throughput-bound and the fusion wins 4 % of the C5 step)
-        fused_topk = planes == 2 && d->corr[i] == nullptr && gemm_ss_topk_ok(gm, (int)lay.P0, LBM_C, gb, k) &&
-                     (k <= g_fuse_kmax_small || Rfull >= 4096);
+        // Row-streaming form (gemm_rs.hip): the MAP streams through LDS, 256 points at a time sit in registers, and every lane
+        // keeps the k best cells of its point across all steps -- no scores leave the accumulators at all.
+        int rs_cand = 0;
+        if (g_rs_topk && planes == 2 && d->corr[i] == nullptr && k <= 9) {
+          rs_cand = gemm_rs_topk_cands((int)lay.P0, gm, gb, k);
+          if (rs_cand < k || rs_cand > 4096 || rs_cand % 4 != 0 || 2ll * rs_cand > lay.P0) rs_cand = 0;
+        }
+        fused_topk = rs_cand > 0 || (planes == 2 && d->corr[i] == nullptr && gemm_ss_topk_ok(gm, (int)lay.P0, LBM_C, gb, k) &&
+                                     (k <= g_fuse_kmax_small || Rfull >= 4096));
         GemmSSArgs g;
         g.planes = planes;
-        if (fused_topk) {
+        if (rs_cand > 0) {
+          n_cand = rs_cand;
+          g.cand_v = cdst;
+          g.cand_i = reinterpret_cast<int*>(cdst + (long long)R * n_cand);
+          g.topk_k = k;
+        } else if (fused_topk) {
           n_cand = (int)((lay.P0 + 127) / 128) * k;
           g.cand_v = cdst;
           g.cand_i = reinterpret_cast<int*>(cdst + (long long)R * n_cand);
@@ -449,7 +463,7 @@ struct Step {
         g.B = (const char*)F + (long long)i * plane * 4; g.b_plane = plane; g.ldb = LBM_C; g.sB = lay.P0 * LBM_C;
         g.Y = cdst; g.ldy = (int)lay.P0; g.sY = (long long)d->N * lay.P0;
         g.M = gm; g.N = (int)lay.P0; g.K = LBM_C; g.batch = gb;
-        if (gemm_ss(g, s)) return -1;
+        if (rs_cand > 0 ? gemm_rs_topk(g, g_rs_dbg, s) : gemm_ss(g, s)) return -1;
       }
       int* idst = d->topk_idx[i] ? d->topk_idx[i] + (long long)lo * k : idx;
       float* rdst = d->ref_points[i] ? d->ref_points[i] + (long long)lo * k * 2 : ref;
@@ -682,6 +696,14 @@ int lbm_hip_debug_set(int32_t key, int32_t value) {
   }
   if (key == 6) {
     g_fuse_kmax_small = value;
+    return 0;
+  }
+  if (key == 13) {
+    g_rs_topk = value;
+    return 0;
+  }
+  if (key == 14) {
+    g_rs_dbg = value;
     return 0;
   }
   if (key == 7) {

@@ -80,6 +80,13 @@ struct GemmSSArgs {
 };
 int gemm_ss(const GemmSSArgs& a, hipStream_t stream);
 bool gemm_ss_topk_ok(int M, int N, int K, int batch, int k);   // would gemm_ss take the fused top-k path for this shape?
+// Row-streaming variant for K = 256 (gemm_rs.hip): B stationary in registers, A streamed through LDS; same arithmetic, bit-identical.
+bool gemm_rs_ok(const GemmSSArgs& a);
+int gemm_rs(const GemmSSArgs& a, int dbg, hipStream_t stream);
+// ... and with the roles swapped for the correlation product + per-point top-k pre-selection: candidates per point
+// (gemm_rs_topk_cands tells how many, a multiple of 4) in cand_v / cand_i [batch * M, n_cand]
+int gemm_rs_topk_cands(int P0, int N, int batch, int k);
+int gemm_rs_topk(const GemmSSArgs& a, int dbg, hipStream_t stream);
 
 // NHWC convolution with split operands staged by LDS-DMA gather (Cin a power of two >= 32).
 struct ConvSSArgs {

@@ -285,6 +285,7 @@ static int launch16(const Gemm16Dev& d, int batch, hipStream_t stream) {
 static int g_force_tile16 = 0;
 static int g_dbg16 = 0;
 static int g_force_conv = 0;
+static long long g_rs_min_rows = 32768;   // measured (scripts/gemm_rs_check.py): below, the 2-step cost of loading the stationary fragments eats the gain
 void conv16_force(int mode) { g_force_conv = mode; }
 void gemm16_force_tile(int t) { g_force_tile16 = t; }
 void gemm16_debug(int flags) { g_dbg16 = flags; }
@@ -1026,6 +1027,10 @@ int gemm_ss(const GemmSSArgs& a, hipStream_t stream) {
   }
   const long long big = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.batch;
   int t = g_force_tile16;
+  // K = 256 and many rows: the row-streaming kernel (weights stationary in registers), gemm_rs.hip.  Debug flags: 256 = never,
+  // 512 = whenever the shape admits it.
+  if (t == 0 && !(g_dbg16 & 256) && a.planes == 2 && gemm_rs_ok(a) && ((g_dbg16 & 512) || a.M >= g_rs_min_rows))
+    return gemm_rs(a, (g_dbg16 >> 12) & 0xfff, stream);
   const long long mid = (long long)((a.M + 63) / 64) * ((a.N + 63) / 64) * a.batch;
   LBM_REQUIRE(a.planes == 1 || a.planes == 2, "gemm_ss: planes must be 1 or 2");
   if (a.planes == 1) {           // hi planes only: the same three tilings, one MFMA per block

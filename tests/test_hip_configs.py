@@ -131,7 +131,7 @@ def test_c5_1080p_dense_grid_long_memory_against_the_oracle_on_sampled_points():
             c, v, r, _ = model.online_forward(vid[:, f].contiguous())
             if t == 3:
                 names = {p["name"] for p in hip.profile_end()}
-                assert any(n.startswith("gemm_ss_topk") for n in names), f"fused top-k product not taken: {sorted(names)}"
+                assert any(n.startswith(("gemm_ss_topk", "gemm_rs_topk")) for n in names), f"fused top-k product not taken: {sorted(names)}"
                 assert "ffn_fused_ss" not in names          # 10 000 rows: the two-product feed-forward
             want = o.step(video[:, f])
             o.check(f"frame {t}", c[sel.cuda()], model.last_logits[0][0][sel.cuda()], model.last_logits[1][0][sel.cuda()], want)

@@ -102,6 +102,17 @@ int lbm_hip_pyramid(float* tokens, int32_t B, int32_t h, int32_t w, lbm_stream_t
 int lbm_hip_corr_maps(const float* tokens, float* inv_norm, float* F, const float* corr_mix_host,
                       int32_t n_layers, int32_t B, int32_t h, int32_t w, lbm_stream_t stream);
 
+/* Correlation product and top-k in one pass: for every point the k cells with the largest q_hat . F_cell (ties -> lowest cell) and
+ * their centres, without the [N, P0] score matrix ever reaching memory.  Replaces the same lines as lbm_hip_corr_maps' consumer +
+ * lbm_hip_topk together (transformer.py:306-308: torch.einsum / conv score + torch.topk; coord_utils.py:4-29).
+ * q: the L2-normalised point tokens as split f16 planes [B, N, 256] (hi plane; lo plane q_plane ELEMENTS further), F: one layer of
+ * lbm_hip_corr_maps' output as split planes [B, P0, 256] (f_plane likewise).  k in 1..9.  workspace: device scratch of
+ * lbm_hip_corr_topk_workspace_bytes(B, N, P0, k) bytes (per-point candidate lists).  val_out (optional): the k scores.            */
+int64_t lbm_hip_corr_topk_workspace_bytes(int32_t B, int32_t N, int32_t P0, int32_t k);
+int lbm_hip_corr_topk(const void* q_hi, int64_t q_plane, const void* f_hi, int64_t f_plane, int32_t B, int32_t N, int32_t P0,
+                      int32_t k, int32_t grid_w, int32_t stride_px, void* workspace, int64_t workspace_bytes, int32_t* idx_out,
+                      float* ref_out, float* val_out, lbm_stream_t stream);
+
 /* Top-k per row (ties -> lowest index) + cell centres (x, y) in network pixels.
  * Replaces torch.topk + indices_to_coords (transformer.py:307-308, coord_utils.py:4-29).        */
 int lbm_hip_topk(const float* corr, int64_t ld, int32_t P, int32_t k, int32_t rows, int32_t grid_w,

@@ -609,6 +609,34 @@ int lbm_hip_topk(const float* corr, int64_t ld, int32_t P, int32_t k, int32_t ro
   return topk_rows(corr, ld, P, k, rows, grid_w, stride_px, idx_out, ref_out, val_out, (hipStream_t)stream);
 }
 
+int64_t lbm_hip_corr_topk_workspace_bytes(int32_t B, int32_t N, int32_t P0, int32_t k) {
+  if (B < 1 || N < 1 || P0 < 1 || k < 1 || k > 9) return -1;
+  const int nc = gemm_rs_topk_cands(P0, N, B, k);
+  return nc < k ? -1 : (int64_t)B * N * nc * 8;
+}
+
+int lbm_hip_corr_topk(const void* q_hi, int64_t q_plane, const void* f_hi, int64_t f_plane, int32_t B, int32_t N, int32_t P0, int32_t k,
+                      int32_t grid_w, int32_t stride_px, void* workspace, int64_t workspace_bytes, int32_t* idx_out, float* ref_out,
+                      float* val_out, lbm_stream_t stream) {
+  LBM_REQUIRE(q_hi && f_hi && workspace && idx_out, "corr_topk: null argument");
+  LBM_REQUIRE(B >= 1 && N >= 1 && P0 >= k && k >= 1 && k <= 9 && grid_w >= 1, "corr_topk: bad shape B=%d N=%d P0=%d k=%d", B, N, P0, k);
+  LBM_REQUIRE(q_plane % 8 == 0 && f_plane % 8 == 0 && ((uintptr_t)q_hi & 15) == 0 && ((uintptr_t)f_hi & 15) == 0 && ((uintptr_t)workspace & 15) == 0,
+              "corr_topk: operands must be 16-byte aligned");
+  const int nc = gemm_rs_topk_cands(P0, N, B, k);
+  LBM_REQUIRE(nc >= k && nc <= 4096 && nc % 4 == 0, "corr_topk: cannot partition %d cells (candidates %d)", P0, nc);
+  const long long R = (long long)B * N;
+  LBM_REQUIRE(workspace_bytes >= R * nc * 8, "corr_topk: workspace of %lld bytes, need %lld", (long long)workspace_bytes, R * nc * 8);
+  GemmSSArgs g;
+  g.A = q_hi; g.a_plane = q_plane; g.lda = LBM_C; g.sA = (long long)N * LBM_C;
+  g.B = f_hi; g.b_plane = f_plane; g.ldb = LBM_C; g.sB = (long long)P0 * LBM_C;
+  g.M = N; g.N = P0; g.K = LBM_C; g.batch = B;
+  g.cand_v = static_cast<float*>(workspace);
+  g.cand_i = reinterpret_cast<int*>(g.cand_v + R * nc);
+  g.topk_k = k;
+  if (gemm_rs_topk(g, g_rs_dbg, (hipStream_t)stream)) return -1;
+  return topk_candidates(g.cand_v, g.cand_i, nc, P0, k, (int)R, grid_w, stride_px, idx_out, ref_out, val_out, (hipStream_t)stream);
+}
+
 int lbm_hip_msda_sample(const lbm_hip_msda_desc* d, lbm_stream_t stream) {
   LBM_REQUIRE(d != nullptr, "msda_sample: null descriptor");
   MsdaArgs a;

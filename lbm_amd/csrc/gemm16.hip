@@ -19,6 +19,13 @@
 #include "gemm.hpp"
 #include "rows.hpp"
 
+// 1: pin all fragment reads of a chunk in front of its MFMAs (sched_barrier).  Measured and left off: with four waves per SIMD the
+// compiler's own interleaving is better here (128 x 128 tile: 48.9 -> 60.6 us at 16384 x 1024 x 256); the row-streaming kernel
+// (gemm_rs.hip, two waves per SIMD) is where the pinning pays.
+#ifndef LBM_PIN
+#define LBM_PIN 0
+#endif
+
 #include <cstdlib>
 #include <set>
 #include <string>
@@ -639,6 +646,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_ss_kernel(GemmSSDev a) {
         if constexpr (NPL == 2) fbl[s][j] = *reinterpret_cast<const half8*>(Bl + offB[j][s]);
       }
     }
+    // Pin the reads in front of the MFMAs: left alone, hipcc sinks each read to just before its first use (one register set, a
+    // full lgkmcnt(0) wait per k-step) and the matrix cores idle for the LDS latency (scripts/micro/mfma_peak.hip, modes 2 / 4).
+#if LBM_PIN
+    __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -911,6 +923,11 @@ static int conv_launch(const ConvSSArgs& c, GemmSSDev& d, int nsplit, int nk, lo
       if (handled) return rc;
     }
     if (big >= 128 && c.Cout > 64) return launch_ss<128, 128, 2, 4, 2, true, false, 0, NPL>(d, 1, stream);
+    // 64 output channels over many pixels (layer1 of a batch of streams): 256 x 64 tiles stage 40 DMA pieces for 96 MFMAs where
+    // 64 x 64 tiles stage 16 for 24 (scripts/conv_bench.py 64: 362 -> 298 us at 786432 x 64 x 576)
+    if constexpr (NPL == 2) {
+      if (c.Cout <= 64 && M >= 65536) return launch_ss<256, 64, 4, 2, 2, true, false, 0, 2>(d, 1, stream);
+    }
     return mid <= 320 ? launch_ss<64, 64, 2, 2, 4, true, false, 0, NPL>(d, 1, stream)
                       : launch_ss<64, 64, 2, 2, 2, true, false, 0, NPL>(d, 1, stream);
   }
@@ -950,7 +967,7 @@ int conv2d_nhwc_ss(const ConvSSArgs& c, hipStream_t stream) {
   const long long big = ((M + 127) / 128) * ((c.Cout + 127) / 128);
   const long long mid = ((M + 63) / 64) * ((c.Cout + 63) / 64);
   int nsplit = 1;
-  if (g_force_conv >= 1 && g_force_conv <= 9) {      // tuning: unsplit pipelined variants
+  if (g_force_conv >= 1 && g_force_conv <= 14) {      // tuning: unsplit pipelined variants
     d.bias = c.bias; d.res = c.res; d.act = c.relu ? ACT_RELU_POST : ACT_NONE;
     d.Y = c.Y; d.Ys = (_Float16*)c.Ys; d.ys_plane = c.ys_plane; d.kt0_per_z = 0;
     switch (g_force_conv) {
@@ -960,6 +977,14 @@ int conv2d_nhwc_ss(const ConvSSArgs& c, hipStream_t stream) {
       case 4: return launch_ss<32, 64, 1, 2, 6, true>(d, 1, stream);
       case 5: return launch_ss<64, 64, 2, 2, 6, true>(d, 1, stream);
       case 6: return launch_ss<32, 32, 1, 1, 6, true>(d, 1, stream);
+      case 7: return launch_ss<128, 64, 2, 2, 2, true>(d, 1, stream);
+      case 8: return launch_ss<256, 64, 4, 2, 2, true>(d, 1, stream);
+      case 9: return launch_ss<256, 64, 4, 1, 2, true>(d, 1, stream);
+      case 10: return launch_ss<256, 128, 4, 2, 2, true>(d, 1, stream);
+      case 11: return launch_ss<128, 256, 2, 4, 2, true>(d, 1, stream);
+      case 12: return launch_ss<128, 128, 2, 4, 2, true>(d, 1, stream);
+      case 13: return launch_ss<128, 128, 2, 2, 2, true>(d, 1, stream);
+      case 14: return launch_ss<64, 64, 2, 2, 2, true>(d, 1, stream);
       default: break;
     }
   }
@@ -1069,6 +1094,8 @@ int gemm_ss(const GemmSSArgs& a, hipStream_t stream) {
     case 18: return launch_ss<128, 64, 4, 2, 3>(d, a.batch, stream);
     case 19: return launch_ss<64, 128, 2, 4, 3>(d, a.batch, stream);
     case 21: return launch_ss<128, 128, 4, 2, 2>(d, a.batch, stream);
+    case 22: return launch_ss<256, 128, 4, 2, 2>(d, a.batch, stream);
+    case 23: return launch_ss<128, 256, 2, 4, 2>(d, a.batch, stream);
     default: break;
   }
   set_error("gemm_ss: unknown tiling %d", t);

@@ -28,7 +28,8 @@ EXPORTS = (
     "lbm_hip_profile_begin", "lbm_hip_profile_end", "lbm_hip_split_planes", "lbm_hip_debug_set", "lbm_hip_linear_ss",
     "lbm_hip_conv2d_nhwc_ss", "lbm_hip_maxpool3x3s2_nhwc_s", "lbm_hip_upcat_s", "lbm_hip_pyramid_s",
     "lbm_hip_update_points", "lbm_hip_encoder_tail", "lbm_hip_pack_fragment_major", "lbm_hip_ffn_slabs",
-    "lbm_hip_debug_ptr", "lbm_hip_update_points_static", "lbm_hip_preprocess_u8",
+    "lbm_hip_debug_ptr", "lbm_hip_update_points_static", "lbm_hip_preprocess_u8", "lbm_hip_corr_topk",
+    "lbm_hip_corr_topk_workspace_bytes",
 )
 
 
@@ -160,6 +161,10 @@ def load() -> C.CDLL:
     lib.lbm_hip_split_planes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.lbm_hip_profile_end.argtypes = [C.POINTER(ProfileEntry), C.c_int32]
     lib.lbm_hip_debug_ptr.argtypes = [C.c_int32, C.c_void_p]
+    lib.lbm_hip_corr_topk_workspace_bytes.restype = C.c_int64
+    lib.lbm_hip_corr_topk_workspace_bytes.argtypes = [C.c_int32] * 4
+    lib.lbm_hip_corr_topk.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                      C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = lib
     return lib
 
@@ -488,6 +493,26 @@ def corr_maps(tokens: torch.Tensor, corr_mix: Sequence[float], n_layers: int, h:
     mix = (C.c_float * (n_layers * 4))(*[float(v) for v in corr_mix])
     _check(load().lbm_hip_corr_maps(_p(tokens), _p(inv), _p(F), mix, n_layers, B, h, w, _stream()), "lbm_hip_corr_maps")
     return F
+
+
+def corr_topk(q: "SplitTensor", F: "SplitTensor", k: int, grid_w: int, stride_px: int = 4):
+    """Correlation product + top-k in one pass (lbm_hip_corr_topk).  q: split planes (B, N, 256), F: split planes (B, P0, 256).
+    Returns (idx int32 (B, N, k), cell centres (B, N, k, 2), scores (B, N, k))."""
+    _require_gpu()
+    B, N, _ = q.shape
+    P0 = F.shape[1]
+    dev = q.planes.device
+    lib = load()
+    nbytes = int(lib.lbm_hip_corr_topk_workspace_bytes(B, N, P0, k))
+    if nbytes < 0:
+        raise HipError("lbm_hip_corr_topk_workspace_bytes: shape not supported")
+    ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+    idx = torch.empty(B, N, k, device=dev, dtype=torch.int32)
+    ref = torch.empty(B, N, k, 2, device=dev, dtype=torch.float32)
+    val = torch.empty(B, N, k, device=dev, dtype=torch.float32)
+    _check(lib.lbm_hip_corr_topk(q.hi, q.plane, F.hi, F.plane, B, N, P0, k, grid_w, stride_px, ws.data_ptr(), nbytes,
+                                 idx.data_ptr(), ref.data_ptr(), val.data_ptr(), _stream()), "lbm_hip_corr_topk")
+    return idx, ref, val
 
 
 def topk(corr: torch.Tensor, k: int, grid_w: int, stride_px: int = 4):

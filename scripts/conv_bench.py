@@ -27,7 +27,8 @@ SHAPES = [  # B, H, W, Cin, Cout, k, stride
     (1, 48, 64, 128, 256, 3, 2), (1, 24, 32, 256, 256, 3, 1), (1, 48, 64, 128, 256, 1, 2),
 ]
 B_ = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-scratch = torch.empty(32 << 20, device="cuda", dtype=torch.uint8)
+MODES = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else list(range(0, 7))
+scratch = torch.empty(32 << 20, device="cuda", dtype=torch.uint8) if B_ == 1 else None
 for (B, H, W, Cin, Cout, k, st) in SHAPES:
     B = B_
     x = hip.SplitTensor((B, H, W, Cin), "cuda")
@@ -37,7 +38,7 @@ for (B, H, W, Cin, Cout, k, st) in SHAPES:
     b = torch.zeros(Cout, device="cuda")
     ref = None
     row = []
-    for mode in range(0, 7):
+    for mode in MODES:
         lib.lbm_hip_debug_set(4, mode)
         y, _ = hip.conv2d_nhwc_ss(x, w, b, k, st, k // 2, True, scratch=scratch)
         if ref is None:
@@ -45,7 +46,7 @@ for (B, H, W, Cin, Cout, k, st) in SHAPES:
         err = float((y - ref).abs().max())
         t, names = timeit(lambda: hip.conv2d_nhwc_ss(x, w, b, k, st, k // 2, True, scratch=scratch))
         row.append("%5.1f%s" % (t, "" if err < 1e-3 else "!ERR%.2g" % err))
-        if mode == 0:
+        if mode == MODES[0]:
             n0 = names
     lib.lbm_hip_debug_set(4, 0)
-    print((B, H, W, Cin, Cout, k, st), " default | 64x64s3 | 64x64s4 | 32x64s4 | 32x64s6 | 64x64s6 | 32x32s6 :", " | ".join(row), "  [", n0, "]", flush=True)
+    print((B, H, W, Cin, Cout, k, st), " modes %s (0 default | 1 64x64s3 | 2 64x64s4 | 3 32x64s4 | 4 32x64s6 | 5 64x64s6 | 6 32x32s6 | 7 128x64 | 8 256x64/8w | 9 256x64/4w | 10 256x128 | 11 128x256 | 12 128x128/8w | 13 128x128/4w | 14 64x64s2):" % MODES, " | ".join(row), "  [", n0, "]", flush=True)

@@ -812,8 +812,9 @@ def test_frame_pipeline_gives_the_same_tracks_as_serial_frames(hip):
 
 
 def test_correlation_product_with_fused_top_k_selects_the_same_cells(hip):
-    """The correlation GEMM that keeps only each 128-column tile's k best per row (taken for k = 9 / 4 from 4096 rows on)
-    against the unfused product + dense top-k, on the same inputs: the selected cells of every layer, and with them every
+    """Three forms of correlation + top-k inside the step, on the same inputs: the row-streaming product with per-point lists
+    (gemm_rs.hip, the default), the tiled product that keeps each 128-column tile's k best per row (debug key 13 = 0, key 6 = 9),
+    and the unfused product + dense top-k (key 13 = 0, key 6 = 0).  The selected cells of every layer, and with them every
     output, must be identical."""
     g = fx.geometry("full256")
     tr, _ = _transformer(g, precision="split")
@@ -821,17 +822,25 @@ def test_correlation_product_with_fused_top_k_selects_the_same_cells(hip):
     lib = hip.load()
     outs = {}
     try:
-        for mode in (9, 0):
-            lib.lbm_hip_debug_set(6, mode)
+        for name, k13, k6 in (("rowstream", 1, 1), ("tiled", 0, 9), ("unfused", 0, 0)):
+            lib.lbm_hip_debug_set(13, k13)
+            lib.lbm_hip_debug_set(6, k6)
+            hip.profile_begin()
             with torch.no_grad():
-                outs[mode] = tr(cu["query"], cu["feat"], cu["stream"], cu["collision"], cu["vis_mask"], cu["mem_mask"], cu["queried"])
+                outs[name] = tr(cu["query"], cu["feat"], cu["stream"], cu["collision"], cu["vis_mask"], cu["mem_mask"], cu["queried"])
+            names = {p["name"] for p in hip.profile_end()}
+            assert any(n.startswith("gemm_rs_topk") for n in names) == (name == "rowstream"), (name, sorted(names))
+            assert any(n.startswith("gemm_ss_topk") for n in names) == (name == "tiled"), (name, sorted(names))
     finally:
+        lib.lbm_hip_debug_set(13, 1)
         lib.lbm_hip_debug_set(6, 1)
-    a, b = outs[9], outs[0]
-    for la, lb in zip(a[0], b[0]):
-        assert torch.equal(la["reference_points"], lb["reference_points"])
-    for i in (2, 3, 4):
-        assert torch.equal(a[i], b[i])
+    b = outs["unfused"]
+    for name in ("rowstream", "tiled"):
+        a = outs[name]
+        for la, lb in zip(a[0], b[0]):
+            assert torch.equal(la["reference_points"], lb["reference_points"]), name
+        for i in (2, 3, 4):
+            assert torch.equal(a[i], b[i]), name
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -1,0 +1,113 @@
+"""Row-streaming split product (lbm_amd/csrc/gemm_rs.hip) through the C ABI.
+
+Linear form: bit-identical to the tiled product (gemm16.hip) on every output kind, ragged shapes included.
+Correlation + top-k form (lbm_hip_corr_topk; transformer.py:306-308, coord_utils.py:4-29): the selected cells, their order,
+scores and centres equal the dense product followed by the dense top-k, bit for bit; exact ties go to the lowest cell
+wherever in the partition (other half-wave, other step, other cell range) the equal cells lie."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from lbm_amd import hip as h
+    h.load()
+    return h
+
+
+def _split(hip, x):
+    t = hip.SplitTensor(tuple(x.shape), "cuda")
+    hip.load().lbm_hip_split_planes(x.data_ptr(), t.hi, t.planes[1].data_ptr(), x.numel(), None)
+    return t
+
+
+@pytest.mark.parametrize("M,N", [(4100, 256), (33, 1456), (5000, 432), (40000, 1024), (1, 256), (31, 8), (257, 260)])
+def test_linear_is_bit_identical_to_the_tiled_product(hip, M, N):
+    lib = hip.load()
+    r = np.random.default_rng(M + N)
+    xs = _split(hip, torch.from_numpy(r.normal(size=(M, 256)).astype(np.float32)).cuda())
+    ws = hip.SplitWeight(torch.from_numpy((r.normal(size=(N, 256)) * 0.1).astype(np.float32)).cuda())
+    b = torch.from_numpy(r.normal(size=(N,)).astype(np.float32)).cuda()
+    res = torch.from_numpy(r.normal(size=(M, N)).astype(np.float32)).cuda()
+    try:
+        for act, use_res, f32, split in [(0, False, True, False), (1, False, False, True), (2, True, True, True), (1, False, True, True)]:
+            out = {}
+            for flag in (256, 512):            # debug key 2: 256 = tiled kernel only, 512 = row-streaming whenever the shape admits it
+                lib.lbm_hip_debug_set(2, flag)
+                out[flag] = hip.linear_ss(xs, ws, b, act=act, res=res if use_res else None, res_scale=0.5, want_f32=f32, want_split=split)
+            (y0, s0), (y1, s1) = out[256], out[512]
+            if f32:
+                assert torch.equal(y0.view(torch.int32), y1.view(torch.int32)), (act, use_res)
+            if split:
+                assert torch.equal(s0.view(torch.int16), s1.view(torch.int16)), (act, use_res)
+    finally:
+        lib.lbm_hip_debug_set(2, 0)
+
+
+def _dense(hip, q, F, k, grid_w):
+    """the unfused path: tiled product into an fp32 score matrix, then the dense top-k kernel"""
+    lib = hip.load()
+    B, N, _ = q.shape
+    idx, ref, val = [], [], []
+    lib.lbm_hip_debug_set(2, 256)
+    try:
+        for b in range(B):
+            qs, fs = hip.SplitTensor((N, 256), "cuda"), hip.SplitTensor((F.shape[1], 256), "cuda")
+            qs.planes.copy_(q.planes[:, b])
+            fs.planes.copy_(F.planes[:, b])
+            corr, _ = hip.linear_ss(qs, fs)
+            i, r, v = hip.topk(corr, k, grid_w)
+            idx.append(i); ref.append(r); val.append(v)
+    finally:
+        lib.lbm_hip_debug_set(2, 0)
+    return torch.stack(idx), torch.stack(ref), torch.stack(val)
+
+
+@pytest.mark.parametrize("B,N,h,w,k", [(1, 1024, 96, 128, 9), (3, 300, 40, 52, 4), (2, 37, 24, 32, 1), (64, 64, 16, 24, 9), (1, 2600, 48, 64, 9)])
+def test_correlation_top_k_equals_dense_product_and_dense_top_k(hip, B, N, h, w, k):
+    g = torch.Generator().manual_seed(B * 1000 + N)
+    qf = torch.nn.functional.normalize(torch.randn(B, N, 256, generator=g), dim=-1).cuda()
+    Ff = (torch.randn(B, h * w, 256, generator=g) * 0.3).cuda()
+    q, F = _split(hip, qf), _split(hip, Ff)
+    idx, ref, val = hip.corr_topk(q, F, k, w)
+    di, dr, dv = _dense(hip, q, F, k, w)
+    assert torch.equal(idx, di.view_as(idx))
+    assert torch.equal(val.view(torch.int32), dv.view_as(val).view(torch.int32))
+    assert torch.equal(ref, dr.view_as(ref))
+
+
+def test_correlation_top_k_breaks_exact_ties_to_the_lowest_cell(hip):
+    """Identical map rows give exactly equal scores.  Copies are planted in the same half-wave, the other half-wave (rows 4 apart),
+    another step (32 apart), another cell range, and as a run of 12 equal cells that must be cut at k."""
+    h, w, k, N = 96, 128, 9, 300
+    P0 = h * w
+    g = torch.Generator().manual_seed(5)
+    qf = torch.nn.functional.normalize(torch.randn(1, N, 256, generator=g), dim=-1)
+    Ff = torch.randn(1, P0, 256, generator=g) * 0.05
+    # every point's own direction, planted (scaled so it wins) at several cells: exact duplicates of one another
+    plant = [7, 8, 11, 7 + 32, 5000, 5000 + 4, 12000, 3, 6001, 9000, 9001, 9002]
+    for n in range(0, N, 3):
+        for c in plant:
+            Ff[0, (c + 13 * n) % P0] = qf[0, n] * 2.0
+    q, F = _split(hip, qf.cuda()), _split(hip, Ff.cuda())
+    idx, ref, val = hip.corr_topk(q, F, k, w)
+    di, dr, dv = _dense(hip, q, F, k, w)
+    assert torch.equal(idx, di.view_as(idx))
+    for n in range(0, N, 3):
+        cells = sorted((c + 13 * n) % P0 for c in plant)
+        got = idx[0, n].tolist()
+        assert got == cells[:k], (n, got, cells[:k])
+        assert len(set(val[0, n].tolist())) == 1            # all k scores exactly equal: the cut was made on the index alone
+
+
+def test_corr_topk_rejects_bad_arguments(hip):
+    q = hip.SplitTensor((1, 8, 256), "cuda")
+    F = hip.SplitTensor((1, 64, 256), "cuda")
+    q.planes.zero_(); F.planes.zero_()
+    with pytest.raises(hip.HipError):
+        hip.corr_topk(q, F, 10, 8)                              # k > 9
+    lib = hip.load()
+    assert lib.lbm_hip_corr_topk_workspace_bytes(1, 8, 64, 0) < 0

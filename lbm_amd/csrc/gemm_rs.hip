@@ -47,7 +47,9 @@ struct GemmRSDev {
   float* cand_v;
   int* cand_i;
   int n_cand;
-  int dbg;   // tuning: 1 = no skew between the waves of a SIMD, 2 = no DMA after the prologue, 4 = no output stores, 8 = no MFMAs
+  int dbg;   // tuning (timing only, results are garbage): 1 no skew between the waves of a SIMD, 2 no DMA after the prologue, 4 no epilogue,
+             // 8 no MFMAs, 16 non-temporal stores, 32 no loads of T, 64 return at once, 128 strict waits, 256 stores into 32 rows, 512 no
+             // transposition, 1024 transposition without stores
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_rs;
@@ -230,13 +232,18 @@ __global__ __launch_bounds__(512) void gemm_rs_kernel(GemmRSDev a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) out[e] = gelu_erf(out[e]);
       }
+      if (!(a.dbg & 512)) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) Tw[(4 * h + (e & 3) + 8 * (e >> 2)) * TP + r] = out[e];
+        for (int e = 0; e < 16; ++e) Tw[(4 * h + (e & 3) + 8 * (e >> 2)) * TP + r] = out[e];
+      }
       // The patch is private to the wave and the LDS serves a wave's requests in order, so the transposed reads need no barrier.  They
       // are issued from inline asm: before a compiler-visible ds_read hipcc waits vmcnt(0) here (it cannot tell the patch from the
       // DMA ring), which would drain the ring and the stores four times per step.
       f32x4 tv[4];
-      {
+      if (a.dbg & 512) {                     // tuning: no transposition (garbage goes out)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tv[i] = f32x4{out[4 * i], out[4 * i + 1], out[4 * i + 2], out[4 * i + 3]};
+      } else {
         const unsigned ta = (unsigned)(uintptr_t)(lds_ptr_rs)(Tw + (lane >> 3) * TP + (lane & 7) * 4);
         asm volatile(
             "s_waitcnt lgkmcnt(0)\n\t"
@@ -256,7 +263,7 @@ __global__ __launch_bounds__(512) void gemm_rs_kernel(GemmRSDev a) {
         const int row = mb + rl, col = n0 + c4 * 4;
         const int srow = (a.dbg & 256) ? (row & 31) : row;     // tuning: all stores into 32 rows (L2-resident)
         float4 v = make_float4(tv[i][0], tv[i][1], tv[i][2], tv[i][3]);
-        if (row < a.Ms && col < a.Nt) {
+        if (row < a.Ms && col < a.Nt && !(a.dbg & 1024)) {   // (1024: tuning, transposition without the stores)
           if (RES && res) {
             int rr = row;
             if (a.res_div != 1) rr /= a.res_div;

@@ -176,7 +176,9 @@ class EncoderWeights:
         for i, (c1, c2, down) in enumerate(self.blocks):
             idn = y if down is None else down.split(ys, False, want_split=False, scratch=self._scratch, planes=self.planes)[0]
             _, ts = c1.split(ys, True, want_f32=False, scratch=self._scratch, planes=self.planes)
-            y, ys = c2.split(ts, True, idn, scratch=self._scratch, planes=self.planes)
+            # the fp32 copy of a block's output is only read as the next block's identity residual
+            nxt = self.blocks[i + 1] if i + 1 < len(self.blocks) else None
+            y, ys = c2.split(ts, True, idn, want_f32=nxt is not None and nxt[2] is None, scratch=self._scratch, planes=self.planes)
             if i % 2 == 1:
                 feats.append(ys)
         qs = [hip.linear_ss(f.reshape(-1, f.shape[-1]), wt, self.lvl_b if i == 0 else None, planes=self.planes)[0]

@@ -61,6 +61,7 @@ ProfScope::~ProfScope() {
 
 // ---- workspace layout of the step --------------------------------------------------------------
 static constexpr unsigned long long Step_kSlabRows = 16384;
+static constexpr unsigned long long Step_kFfnRowsMax = 16384;   // most rows for the many-rows fused feed-forward (its 8 slabs: 128 MB)
 
 
 struct StepLayout {
@@ -131,7 +132,13 @@ static int build_layout(const lbm_hip_step_desc* d, StepLayout& lay) {
   lay.add("pred", (unsigned long long)lay.R * 2 * f);
   lay.add("coll_tok", (unsigned long long)lay.R * LBM_C * f);
   lay.add("preq", (unsigned long long)lay.Q * LBM_C * f);                   // pre-LayerNorm rows
-  lay.add("slab", 4ull * Step_kSlabRows * LBM_C * f);                       // K-split partial products, one region per sub-run
+  // K-split partial products, one region per sub-run; an undivided run may use all of it for the eight slabs of the many-rows
+  // feed-forward (ffn_rows, up to Step_kFfnRowsMax rows)
+  {
+    const unsigned long long q = (unsigned long long)(lay.Q < (long long)Step_kFfnRowsMax ? lay.Q : (long long)Step_kFfnRowsMax);
+    const unsigned long long rows = 8ull * q > 4ull * Step_kSlabRows ? 8ull * q : 4ull * Step_kSlabRows;
+    lay.add("slab", rows * LBM_C * f);
+  }
   lay.add("hidR", (unsigned long long)lay.R * LBM_C * f);
   if (d->precision >= 1) {   // split twins (two f16 planes = the same number of bytes as the fp32 tensor)
     if (d->tokens_split == nullptr) lay.add("tok_s", (unsigned long long)d->B * lay.L * LBM_C * f);
@@ -152,6 +159,8 @@ static int g_rs_topk = 1;           // tuning (debug key 13): 0 = the correlatio
 static int g_rs_dbg = 0;            // tuning (debug key 14): ablation bits handed to gemm_rs_topk
 static int g_fuse_kmax_small = 1;   // tuning (debug key 6): largest k fused into the correlation product at < 4096 rows
 static int g_ffn_sites = 63;        // tuning (debug key 8): 1 attention blocks, 2 lattice blocks, 4 head blocks may fuse
+extern int g_ffn_rows_dbg;          // ffn.hip (debug key 16)
+static int g_ffn_rows_mode = 0;     // tuning (debug key 15): 0 = many-rows fused feed-forward from g_ffn_fused_rows + 1 rows on, 1 = never, 2 = for any row count
 static int g_ffn_fused_rows = 2048; // tuning (debug key 7): most rows for which the feed-forward runs as one fused launch (0: never)
 
 struct TV {
@@ -173,6 +182,10 @@ struct Step {
   long long Rfull = 0;
   int lo = 0, R = 0, sub = 0, nsub = 1;
   static constexpr long long kSlabRows = 16384;  // per-sub-run slab capacity (rows of 256 floats): K-split / feed-forward partial outputs
+  long long slab_rows_total() const {               // the whole "slab" buffer (an undivided run may use all of it)
+    const long long q = lay.Q < (long long)Step_kFfnRowsMax ? lay.Q : (long long)Step_kFfnRowsMax;
+    return 8 * q > 4 * kSlabRows ? 8 * q : 4 * kSlabRows;
+  }
 
   template <typename T>
   T* buf(const char* name) {
@@ -268,7 +281,11 @@ struct Step {
              const TV& Y, const uint8_t* keep = nullptr, const float* fallback = nullptr, const TV* Yn = nullptr, const TV* hid = nullptr,
              int site = 1) {
     const bool fused = (g_ffn_sites & site) && split && M <= g_ffn_fused_rows && 8ll * M <= kSlabRows && W(wb + f1fm) != nullptr && W(wb + f2fm) != nullptr;
-    if (!fused) {
+    // many rows: the same eight slabs from the kernel that keeps the weights in registers and streams the rows (ffn.hip)
+    const bool rows_path = (g_ffn_sites & site) && split && planes == 2 && nsub == 1 && g_ffn_rows_mode != 1 &&
+                           (g_ffn_rows_mode == 2 || M > g_ffn_fused_rows) && M <= (long long)Step_kFfnRowsMax && 8ll * M <= slab_rows_total() &&
+                           W(wb + f1fm) != nullptr && W(wb + f2fm) != nullptr;
+    if (!fused && !rows_path) {
       if (linear(X, LBM_C, wb + f1w, wb + f1b, *hid, 1024, M, 1024, LBM_C, ACT_GELU)) return -1;
       return linear_ln(*hid, 1024, wb + f2w, wb + f2b, 1, M, 1024, res, 1, 1.f, wb + g, wb + be, Y, keep, fallback, Yn);
     }
@@ -276,7 +293,7 @@ struct Step {
     f.A = X.s; f.a_plane = X.plane; f.lda = LBM_C; f.F1 = d->weights[wb + f1fm]; f.b1 = W(wb + f1b); f.F2 = d->weights[wb + f2fm];
     f.slabs = buf<float>("slab") + (long long)sub * kSlabRows * LBM_C; f.slab_stride = (long long)M * LBM_C;
     f.M = M; f.chunk = 128; f.planes = planes;
-    if (ffn_fused(f, s)) return -1;
+    if (rows_path ? ffn_rows(f, s) : ffn_fused(f, s)) return -1;
     RowsIn in;
     in.X = f.slabs; in.nslab = 8; in.slab_stride = f.slab_stride; in.bias = W(wb + f2b); in.res = res; in.res_div = 1; in.res_scale = 1.f;
     RowsOut o;
@@ -730,6 +747,14 @@ int lbm_hip_debug_set(int32_t key, int32_t value) {
     g_rs_topk = value;
     return 0;
   }
+  if (key == 15) {
+    g_ffn_rows_mode = value;
+    return 0;
+  }
+  if (key == 16) {
+    lbm::g_ffn_rows_dbg = value;
+    return 0;
+  }
   if (key == 14) {
     g_rs_dbg = value;
     return 0;
@@ -839,6 +864,7 @@ int lbm_hip_ffn_slabs(const void* A, int64_t a_plane, int32_t lda, const void* F
   FfnArgs f;
   f.A = A; f.a_plane = a_plane; f.lda = lda; f.F1 = F1_fm; f.b1 = b1; f.F2 = F2_fm; f.slabs = slabs; f.slab_stride = slab_stride;
   f.M = M; f.chunk = 128; f.planes = planes == 1 ? 1 : 2;
+  if (f.planes == 2 && g_ffn_rows_mode != 1 && (g_ffn_rows_mode == 2 || M > g_ffn_fused_rows)) return ffn_rows(f, (hipStream_t)stream);
   return ffn_fused(f, (hipStream_t)stream);
 }
 

@@ -186,6 +186,222 @@ __global__ __launch_bounds__(256) void ffn_fused_kernel(FfnDev a) {
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// The same feed-forward for MANY rows (2048 < M <= 16384: the lattice blocks of a dense grid, a batch of streams).
+//
+// The few-rows kernel above re-reads its 256 KB of weight fragments for every 32 rows; from a few thousand rows on that is more L2
+// traffic than the work is worth (111 against 85 us for the two products at 16384 rows).  Here the weights stay put: a workgroup of
+// 8 waves owns one 128-channel chunk of the hidden layer for a whole RANGE of rows and streams the rows through in steps of 32.
+// Waves 0-3 hold the first layer's fragments of the chunk (32 hidden channels each, all 256 k: 128 VGPRs) and turn a step's rows
+// into the [32, 128] hidden piece (GELU, split planes, LDS); waves 4-7 hold the second layer's fragments (two 32-column output tiles
+// each over the chunk's 128 k: 128 VGPRs) and multiply the PREVIOUS step's hidden piece into the step's partial [32, 256] output.
+// Producer and consumer of a SIMD (waves w and w + 4) share its matrix pipe, so the producer's GELU / split arithmetic sits under
+// the consumer's MFMAs (the activation of step k - 1 is applied at the START of step k, while the consumers multiply step k - 2, and
+// the producers multiply while the consumers store); hidden piece and row tile are double-buffered in LDS, one barrier per step.  The next
+// step's rows are fetched into registers a step ahead.  Output: the same eight K-split slabs as above, bit for bit.
+// ------------------------------------------------------------------------------------------------------------------------
+int g_ffn_rows_dbg = 0;   // debug key 16: ablation bits of ffn_rows_kernel
+
+struct FfnRowsDev {
+  FfnDev f;
+  int steps_total, spg;      // 32-row steps in all / per workgroup
+  int dbg;                   // tuning (timing only): 1 no activation arithmetic, 2 no slab stores, 4 no hidden-piece LDS writes, 8 no producer MFMAs, 16 no consumer MFMAs
+};
+
+__global__ __launch_bounds__(512) void ffn_rows_kernel(FfnRowsDev aa) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int CH = 128, KS1 = kC / 16, KS2 = CH / 16, HP = CH + 8, AP = kC + 8;
+  __shared__ __attribute__((aligned(16))) _Float16 sA[2][2][kRows * AP];
+  __shared__ __attribute__((aligned(16))) _Float16 sH[2][2][kRows * HP];
+  const FfnDev& a = aa.f;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wq = w & 3;
+  const bool producer = w < 4;
+  const int r = lane & 31, h = lane >> 5;
+  const int c = blockIdx.x;
+  const int s0 = blockIdx.y * aa.spg;
+  const int ns = min(aa.spg, aa.steps_total - s0);
+  if (ns <= 0) return;
+  auto handover = [&]() __attribute__((always_inline)) {
+    // LDS writes of this wave have landed; loads and stores to global memory stay in flight (no __syncthreads: its fence would drain them)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+
+  if (producer) {
+    half8 b1h[KS1], b1l[KS1];
+    {
+      const int nb = c * (CH / 32) + wq;
+      const _Float16* p = a.F1 + ((long long)nb * KS1 * 2) * 512 + lane * 8;
+#pragma unroll
+      for (int ks = 0; ks < KS1; ++ks) {
+        b1h[ks] = *reinterpret_cast<const half8*>(p + (ks * 2) * 512);
+        b1l[ks] = *reinterpret_cast<const half8*>(p + (ks * 2 + 1) * 512);
+      }
+    }
+    const int cl = wq * 32 + r;                       // hidden channel inside the chunk: this lane's accumulator column
+    const float bv = a.b1[c * CH + cl];
+    // row tile: 32 rows x 2 planes x 32 pieces of 16 bytes over the 256 producer lanes = 8 pieces per lane
+    const int ptid = tid;                             // 0..255
+    half8 xr[2][4];
+    auto fetch = [&](const int step) __attribute__((always_inline)) {
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int piece = it * 256 + ptid;
+          const int row = piece >> 5, pc = piece & 31;
+          const int m = min((s0 + step) * kRows + row, a.M - 1);
+          xr[pl][it] = *reinterpret_cast<const half8*>(a.A + pl * a.a_plane + (long long)m * a.lda + pc * 8);
+        }
+    };
+    auto stash = [&](const int b) __attribute__((always_inline)) {
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int piece = it * 256 + ptid;
+          const int row = piece >> 5, pc = piece & 31;
+          *reinterpret_cast<half8*>(&sA[b][pl][row * AP + pc * 8]) = xr[pl][it];
+        }
+    };
+    fetch(0);
+    stash(0);
+    if (ns > 1) fetch(1);
+    float sv[16];                                     // step k - 1 before the activation: its GELU runs while the consumers multiply
+    for (int k = 0; k <= ns + 1; ++k) {
+      handover();
+      if (k >= 1 && k <= ns) {
+        _Float16* Hh = &sH[(k - 1) & 1][0][cl];
+        _Float16* Hl = &sH[(k - 1) & 1][1][cl];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int rl = (e & 3) + 8 * (e >> 2) + 4 * h;
+          const float v = (aa.dbg & 1) ? sv[e] : __builtin_amdgcn_fmed3f(gelu_erf(sv[e]), -65000.f, 65000.f);
+          const _Float16 hh = (_Float16)v;
+          if (!(aa.dbg & 4)) {
+            Hh[rl * HP] = hh;
+            Hl[rl * HP] = (_Float16)((v - (float)hh) * 2048.f);
+          }
+        }
+      }
+      if (k >= ns) continue;
+      if (k + 1 < ns) {
+        stash((k + 1) & 1);                           // (that buffer was last read in step k - 1)
+        if (k + 2 < ns) fetch(k + 2);
+      }
+      const _Float16* Ah = &sA[k & 1][0][r * AP + h * 8];
+      const _Float16* Al = &sA[k & 1][1][r * AP + h * 8];
+      f32x16 acc, acx;
+      half8 fa[2][4];
+      auto ldg = [&](const int bsel, const int g) __attribute__((always_inline)) {
+        fa[bsel][0] = *reinterpret_cast<const half8*>(Ah + (2 * g) * 16);
+        fa[bsel][1] = *reinterpret_cast<const half8*>(Al + (2 * g) * 16);
+        fa[bsel][2] = *reinterpret_cast<const half8*>(Ah + (2 * g + 1) * 16);
+        fa[bsel][3] = *reinterpret_cast<const half8*>(Al + (2 * g + 1) * 16);
+      };
+      const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (!(aa.dbg & 8)) ldg(0, 0);
+#pragma unroll
+      for (int g = 0; g < ((aa.dbg & 8) ? 0 : KS1 / 2); ++g) {
+        if (g + 1 < KS1 / 2) ldg((g + 1) & 1, g + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int ks = 2 * g + q;
+          const bool first = ks == 0;
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[g & 1][2 * q], b1h[ks], first ? zero16 : acc, 0, 0, 0);
+          acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[g & 1][2 * q], b1l[ks], first ? zero16 : acx, 0, 0, 0);
+          acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[g & 1][2 * q + 1], b1h[ks], acx, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sv[e] = (acc[e] + acx[e] * (1.0f / 2048.0f)) + bv;
+    }
+  } else {
+    half8 b2h[2][KS2], b2l[2][KS2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int nb = wq * 2 + j;
+      const _Float16* p = a.F2 + (((long long)nb * (kHid / 16) + c * KS2) * 2) * 512 + lane * 8;
+#pragma unroll
+      for (int ks = 0; ks < KS2; ++ks) {
+        b2h[j][ks] = *reinterpret_cast<const half8*>(p + (ks * 2) * 512);
+        b2l[j][ks] = *reinterpret_cast<const half8*>(p + (ks * 2 + 1) * 512);
+      }
+    }
+    float* out = a.slabs + (long long)c * a.slab_stride;
+    for (int k = 0; k <= ns + 1; ++k) {
+      handover();
+      if (k < 2) continue;
+      const _Float16* Hh = &sH[k & 1][0][r * HP + h * 8];          // the hidden piece of step k - 2
+      const _Float16* Hl = &sH[k & 1][1][r * HP + h * 8];
+      f32x16 o[2], ox[2];
+      const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      half8 fh[2][4];
+      auto ldg = [&](const int bsel, const int g) __attribute__((always_inline)) {
+        fh[bsel][0] = *reinterpret_cast<const half8*>(Hh + (2 * g) * 16);
+        fh[bsel][1] = *reinterpret_cast<const half8*>(Hl + (2 * g) * 16);
+        fh[bsel][2] = *reinterpret_cast<const half8*>(Hh + (2 * g + 1) * 16);
+        fh[bsel][3] = *reinterpret_cast<const half8*>(Hl + (2 * g + 1) * 16);
+      };
+      if (!(aa.dbg & 16)) ldg(0, 0);
+#pragma unroll
+      for (int g = 0; g < ((aa.dbg & 16) ? 0 : KS2 / 2); ++g) {
+        if (g + 1 < KS2 / 2) ldg((g + 1) & 1, g + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int ks = 2 * g + q;
+          const bool first = ks == 0;
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            o[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[g & 1][2 * q], b2h[j][ks], first ? zero16 : o[j], 0, 0, 0);
+            ox[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[g & 1][2 * q], b2l[j][ks], first ? zero16 : ox[j], 0, 0, 0);
+            ox[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[g & 1][2 * q + 1], b2h[j][ks], ox[j], 0, 0, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const int m0 = (s0 + k - 2) * kRows;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = (wq * 2 + j) * 32 + r;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = m0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (row < a.M && !(aa.dbg & 2)) out[(long long)row * kC + col] = o[j][e] + ox[j][e] * (1.0f / 2048.0f);
+        }
+      }
+    }
+  }
+#endif
+}
+
+int ffn_rows(const FfnArgs& f, hipStream_t stream) {
+  if (f.M == 0) return 0;
+  LBM_REQUIRE(f.A && f.F1 && f.b1 && f.F2 && f.slabs && f.M > 0, "ffn_rows: null argument");
+  LBM_REQUIRE(f.chunk == 128 && f.planes == 2, "ffn_rows: chunk must be 128, planes 2");
+  LBM_REQUIRE(f.lda % 8 == 0 && f.a_plane % 8 == 0 && ((uintptr_t)f.A & 15) == 0 && ((uintptr_t)f.F1 & 15) == 0 && ((uintptr_t)f.F2 & 15) == 0,
+              "ffn_rows: operands must admit 16-byte pieces");
+  LBM_REQUIRE(f.slab_stride >= (long long)f.M * kC, "ffn_rows: slabs overlap");
+  FfnRowsDev d;
+  d.f.A = (const _Float16*)f.A; d.f.a_plane = f.a_plane; d.f.lda = f.lda; d.f.F1 = (const _Float16*)f.F1; d.f.b1 = f.b1; d.f.F2 = (const _Float16*)f.F2;
+  d.f.slabs = f.slabs; d.f.slab_stride = f.slab_stride; d.f.M = f.M;
+  d.dbg = g_ffn_rows_dbg;
+  d.steps_total = (f.M + kRows - 1) / kRows;
+  int groups = std::min(d.steps_total, 32);             // 8 chunks x 32 row ranges = one workgroup per CU
+  d.spg = (d.steps_total + groups - 1) / groups;
+  groups = (d.steps_total + d.spg - 1) / d.spg;
+  const dim3 grid(kHid / 128, groups);
+  const double flops = 4.0 * f.M * kC * kHid;
+  const double bytes = 4.0 * (f.M * kC + 2.0 * kC * kHid) + 4.0 * f.M * kC * 8;
+  ProfScope prof("ffn_rows_ss", stream, flops, bytes);
+  hipLaunchKernelGGL(ffn_rows_kernel, grid, dim3(512), 0, stream, d);
+  return check_launch("ffn_rows");
+}
+
 int g_ffn_claim = 0;   // debug key 12: 1 = the wave claims the whole register file (see the kernel)
 
 int ffn_fused(const FfnArgs& f, hipStream_t stream) {

@@ -122,6 +122,7 @@ struct FfnArgs {
   int M = 0, chunk = 128, planes = 2;
 };
 int ffn_fused(const FfnArgs& f, hipStream_t stream);
+int ffn_rows(const FfnArgs& f, hipStream_t stream);     // the same slabs for many rows: weights stationary, rows streamed (ffn.hip)
 int pack_fragment_major(const void* hi, const void* lo, int N, int K, void* out, hipStream_t stream);
 
 }  // namespace lbm

@@ -111,3 +111,31 @@ def test_corr_topk_rejects_bad_arguments(hip):
         hip.corr_topk(q, F, 10, 8)                              # k > 9
     lib = hip.load()
     assert lib.lbm_hip_corr_topk_workspace_bytes(1, 8, 64, 0) < 0
+
+
+def _ffn_operands(hip, M, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    W1 = (torch.randn(1024, 256, generator=g) / 16).cuda()
+    b1 = (torch.randn(1024, generator=g) * 0.1).cuda()
+    W2 = (torch.randn(256, 1024, generator=g) / 32).cuda()
+    x = torch.randn(M, 256, generator=g).cuda()
+    f1, f2 = hip.fragment_major(hip.SplitWeight(W1)), hip.fragment_major(hip.SplitWeight(W2))
+    return W1, b1, W2, x, _split(hip, x), f1, f2
+
+
+@pytest.mark.parametrize("M", [1, 33, 1024, 2050, 4100, 9216])
+def test_many_rows_feed_forward_leaves_the_same_slabs_as_the_few_rows_kernel(hip, M):
+    """ffn_rows_kernel (weights stationary, rows streamed; debug key 15 = 2) against ffn_fused_kernel (key 15 = 1): the eight
+    partial outputs must be bit-identical -- same MFMAs in the same order -- and their sum must meet the fp64 bar."""
+    lib = hip.load()
+    W1, b1, W2, x, xs, f1, f2 = _ffn_operands(hip, M, 100 + M)
+    try:
+        lib.lbm_hip_debug_set(15, 1)
+        a = hip.ffn_slabs(xs, f1, b1, f2)
+        lib.lbm_hip_debug_set(15, 2)
+        b = hip.ffn_slabs(xs, f1, b1, f2)
+    finally:
+        lib.lbm_hip_debug_set(15, 0)
+    assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    want = torch.nn.functional.gelu(x.double() @ W1.double().t() + b1.double()) @ W2.double().t()
+    assert float((b.sum(0).double() - want).abs().max()) < 2e-5 * max(1.0, float(want.abs().max()))

@@ -160,6 +160,7 @@ static int g_rs_dbg = 0;            // tuning (debug key 14): ablation bits hand
 static int g_fuse_kmax_small = 1;   // tuning (debug key 6): largest k fused into the correlation product at < 4096 rows
 static int g_ffn_sites = 63;        // tuning (debug key 8): 1 attention blocks, 2 lattice blocks, 4 head blocks may fuse
 extern int g_ffn_rows_dbg;          // ffn.hip (debug key 16)
+static int g_head_pair = 1;         // tuning (debug key 17): 0 = offset and visibility heads as two separate chains
 static int g_ffn_rows_mode = 0;     // tuning (debug key 15): 0 = many-rows fused feed-forward from g_ffn_fused_rows + 1 rows on, 1 = never, 2 = for any row count
 static int g_ffn_fused_rows = 2048; // tuning (debug key 7): most rows for which the feed-forward runs as one fused launch (0: never)
 
@@ -378,6 +379,98 @@ struct Step {
                   LBM_W_MSDA_LN2G, LBM_W_MSDA_LN2B, Q, la.f, out, nullptr, nullptr, nullptr, &hid, wb >= d->n_layers * LBM_W_LAYER_COUNT ? 4 : 2);
   }
 
+
+  // Offset head and visibility head as ONE batch of two (transformer.py:103-149): both sample the same points at the same cell
+  // centres with the same shapes and differ only in their value map and weights, so every launch of the pair -- sampling, output
+  // projection, LayerNorm, feed-forward, LayerNorm, first layer of the read-out MLP -- covers 2 R rows with two parameter sets
+  // (6 launches fewer per frame; identical arithmetic per row, so the results are bit-identical to the two separate chains).
+  // Returns 1 when done (hidden layers of the two read-out MLPs in hid2[0:R] / hid2[R:2R]), 0 when not applicable, -1 on error.
+  int heads_pair(int hb, const TV& x, const float* ref, const float* ol3, int c_off, int c_vis, int ld3, float** hid2_out) {
+    const int wa = hb + LBM_W_HEAD_OFFSET, wbv = hb + LBM_W_HEAD_VIS;
+    if (!g_head_pair || !split || planes != 2 || nsub != 1 || lo != 0 || ol3 == nullptr || lay.kmax < 2 || 16ll * R > kSlabRows) return 0;
+    const int pairs[][2] = {{wa + LBM_W_MSDA_OUTW, wbv + LBM_W_MSDA_OUTW}, {hb + LBM_W_HEAD_OFFH_W0, hb + LBM_W_HEAD_VISH_W0}};
+    for (const auto& pr : pairs) {
+      const long long diff = (const char*)d->weights[pr[1]] - (const char*)d->weights[pr[0]];
+      if (lo_plane(pr[0]) != lo_plane(pr[1]) || diff % 16 != 0) return 0;
+    }
+    if (W(wa + LBM_W_MSDA_F1FM) == nullptr || W(wa + LBM_W_MSDA_F2FM) == nullptr || W(wbv + LBM_W_MSDA_F1FM) == nullptr ||
+        W(wbv + LBM_W_MSDA_F2FM) == nullptr || !(g_ffn_sites & 4))
+      return 0;
+    const long long RC = (long long)R * LBM_C;
+    TV samp2, la2, out2;
+    samp2.s = buf<char>("samp"); samp2.plane = 2 * RC;
+    la2.f = buf<float>("la"); la2.s = buf<char>("la_s"); la2.plane = 2 * RC;
+    out2.s = buf<char>("lb_s"); out2.plane = 2 * RC;
+    float* pre = buf<float>("preq");
+    float* hid2 = buf<float>("lb");
+    // sampling: rows [0, R) from the offset head's value map and offsets, rows [R, 2R) from the visibility head's
+    MsdaArgs m;
+    m.value = buf<float>("value") + (long long)d->n_layers * LBM_C;
+    m.set_value_off = 2ll * LBM_C;                       // value maps: n_layers = offset, + 1 = collision memory, + 2 = visibility
+    m.ldv = lay.n_vmaps * LBM_C;
+    m.v_batch_stride = lay.L * m.ldv;
+    int st = 0;
+    for (int l = 0; l < 4; ++l) {
+      m.lvl_h[l] = h >> l; m.lvl_w[l] = w >> l; m.lvl_start[l] = st;
+      st += (h >> l) * (w >> l);
+    }
+    m.B = d->B; m.N = d->N; m.k = 1; m.P = d->n_points;
+    m.offlog = ol3 + c_off; m.ld_offlog = ld3; m.logit_col = 32 * d->n_points; m.set_offlog_off = c_vis - c_off;
+    m.set_rows = R;
+    m.ref = ref; m.net_w = (float)d->net_w; m.net_h = (float)d->net_h;
+    m.out_s = samp2.s; m.out_plane = samp2.plane;
+    if (msda_sample(m, s)) return -1;
+    auto wdiff = [&](int ia, int ib) { return ((const char*)d->weights[ib] - (const char*)d->weights[ia]) / 2; };   // f16 elements
+    // output projection of both (K = 256: no K-split, the batch dimension is free for the pair)
+    {
+      GemmSSArgs a;
+      a.planes = 2;
+      a.A = samp2.s; a.a_plane = samp2.plane; a.lda = LBM_C; a.sA = RC;
+      a.B = d->weights[wa + LBM_W_MSDA_OUTW]; a.b_plane = lo_plane(wa + LBM_W_MSDA_OUTW); a.ldb = LBM_C;
+      a.sB = wdiff(wa + LBM_W_MSDA_OUTW, wbv + LBM_W_MSDA_OUTW);
+      a.Y = pre; a.ldy = LBM_C; a.sY = RC; a.M = R; a.N = LBM_C; a.K = LBM_C; a.batch = 2;
+      if (gemm_ss(a, s)) return -1;
+    }
+    {   // 2 q + output_proj(.) -> LayerNorm  (msdeformattn.py:185, transformer.py:321)
+      RowsIn in;
+      in.X = pre; in.bias = W(wa + LBM_W_MSDA_OUTB); in.bias2 = W(wbv + LBM_W_MSDA_OUTB);
+      in.res = x.f; in.res2 = x.f; in.res_div = 1; in.res_scale = 2.f; in.set_rows = R;
+      in.gamma2 = W(wbv + LBM_W_MSDA_LN1G); in.beta2 = W(wbv + LBM_W_MSDA_LN1B);
+      RowsOut o;
+      o.Y = la2.f; o.Ys = la2.s; o.ys_plane = la2.plane;
+      if (layernorm_rows_in(in, W(wa + LBM_W_MSDA_LN1G), W(wa + LBM_W_MSDA_LN1B), 2 * R, nullptr, nullptr, o, s)) return -1;
+    }
+    {   // feed-forward + LayerNorm
+      FfnArgs f;
+      f.A = la2.s; f.a_plane = la2.plane; f.lda = LBM_C;
+      f.F1 = d->weights[wa + LBM_W_MSDA_F1FM]; f.b1 = W(wa + LBM_W_MSDA_F1B); f.F2 = d->weights[wa + LBM_W_MSDA_F2FM];
+      f.F1b = d->weights[wbv + LBM_W_MSDA_F1FM]; f.b1b = W(wbv + LBM_W_MSDA_F1B); f.F2b = d->weights[wbv + LBM_W_MSDA_F2FM];
+      f.set_rows = R;
+      f.slabs = buf<float>("slab"); f.slab_stride = 2 * RC; f.M = 2 * R; f.chunk = 128; f.planes = 2;
+      if (ffn_fused(f, s)) return -1;
+      RowsIn in;
+      in.X = f.slabs; in.nslab = 8; in.slab_stride = f.slab_stride;
+      in.bias = W(wa + LBM_W_MSDA_F2B); in.bias2 = W(wbv + LBM_W_MSDA_F2B);
+      in.res = la2.f; in.res2 = la2.f + RC; in.res_div = 1; in.res_scale = 1.f; in.set_rows = R;
+      in.gamma2 = W(wbv + LBM_W_MSDA_LN2G); in.beta2 = W(wbv + LBM_W_MSDA_LN2B);
+      RowsOut o;
+      o.Ys = out2.s; o.ys_plane = out2.plane;
+      if (layernorm_rows_in(in, W(wa + LBM_W_MSDA_LN2G), W(wa + LBM_W_MSDA_LN2B), 2 * R, nullptr, nullptr, o, s)) return -1;
+    }
+    {   // first layers of the two read-out MLPs (Linear + GELU)
+      GemmSSArgs a;
+      a.planes = 2;
+      a.A = out2.s; a.a_plane = out2.plane; a.lda = LBM_C; a.sA = RC;
+      a.B = d->weights[hb + LBM_W_HEAD_OFFH_W0]; a.b_plane = lo_plane(hb + LBM_W_HEAD_OFFH_W0); a.ldb = LBM_C;
+      a.sB = wdiff(hb + LBM_W_HEAD_OFFH_W0, hb + LBM_W_HEAD_VISH_W0);
+      a.bias = W(hb + LBM_W_HEAD_OFFH_B0); a.sBias = W(hb + LBM_W_HEAD_VISH_B0) - W(hb + LBM_W_HEAD_OFFH_B0);
+      a.Y = hid2; a.ldy = LBM_C; a.sY = RC; a.M = R; a.N = LBM_C; a.K = LBM_C; a.batch = 2; a.act = ACT_GELU;
+      if (gemm_ss(a, s)) return -1;
+    }
+    *hid2_out = hid2;
+    return 1;
+  }
+
   // ---- per-frame, point-independent work: split tokens, the six value maps, the correlation maps ----
   int run_frame() {
     const int hb = d->n_layers * LBM_W_LAYER_COUNT;
@@ -524,14 +617,25 @@ struct Step {
     const int c_off = 0, c_cm = 48 * d->n_points, c_vis = c_cm + 48 * d->n_points_cmem, ld3 = c_vis + 48 * d->n_points;
     const bool m3 = W(hb + LBM_W_HEAD_OL3_W) != nullptr && ld3 <= 48 * 16 + 1024;
     if (m3 && linear(x, LBM_C, hb + LBM_W_HEAD_OL3_W, hb + LBM_W_HEAD_OL3_B, ol3, ld3, R, ld3, LBM_C)) return -1;
-    if (msda_block(hb + LBM_W_HEAD_OFFSET, d->n_layers, d->n_points, x, ref, 1, ta, m3 ? ol3.f + c_off : nullptr, ld3)) return -1;
-    if (linear(ta, LBM_C, hb + LBM_W_HEAD_OFFH_W0, hb + LBM_W_HEAD_OFFH_B0, hidR, LBM_C, R, LBM_C, LBM_C, ACT_GELU)) return -1;
-    if (offset_final(hidR.f, W(hb + LBM_W_HEAD_OFFH_W3), W(hb + LBM_W_HEAD_OFFH_B3), ref, (float)d->stride, offset, pred, R, s)) return -1;
-    if (msda_block(hb + LBM_W_HEAD_CMEM, d->n_layers + 1, d->n_points_cmem, x, pred, 1, coll_tok, m3 ? ol3.f + c_cm : nullptr, ld3)) return -1;
-    if (msda_block(hb + LBM_W_HEAD_VIS, d->n_layers + 2, d->n_points, x, ref, 1, ta, m3 ? ol3.f + c_vis : nullptr, ld3)) return -1;
-    if (linear(ta, LBM_C, hb + LBM_W_HEAD_VISH_W0, hb + LBM_W_HEAD_VISH_B0, hidR, LBM_C, R, LBM_C, LBM_C, ACT_GELU)) return -1;
+    float* hid2 = nullptr;
+    const int paired = heads_pair(hb, x, ref, m3 ? ol3.f : nullptr, c_off, c_vis, ld3, &hid2);
+    if (paired < 0) return -1;
+    const float* vis_hidden = nullptr;
+    if (paired) {
+      if (offset_final(hid2, W(hb + LBM_W_HEAD_OFFH_W3), W(hb + LBM_W_HEAD_OFFH_B3), ref, (float)d->stride, offset, pred, R, s)) return -1;
+      if (msda_block(hb + LBM_W_HEAD_CMEM, d->n_layers + 1, d->n_points_cmem, x, pred, 1, coll_tok, m3 ? ol3.f + c_cm : nullptr, ld3)) return -1;
+      vis_hidden = hid2 + (long long)R * LBM_C;
+    } else {
+      if (msda_block(hb + LBM_W_HEAD_OFFSET, d->n_layers, d->n_points, x, ref, 1, ta, m3 ? ol3.f + c_off : nullptr, ld3)) return -1;
+      if (linear(ta, LBM_C, hb + LBM_W_HEAD_OFFH_W0, hb + LBM_W_HEAD_OFFH_B0, hidR, LBM_C, R, LBM_C, LBM_C, ACT_GELU)) return -1;
+      if (offset_final(hidR.f, W(hb + LBM_W_HEAD_OFFH_W3), W(hb + LBM_W_HEAD_OFFH_B3), ref, (float)d->stride, offset, pred, R, s)) return -1;
+      if (msda_block(hb + LBM_W_HEAD_CMEM, d->n_layers + 1, d->n_points_cmem, x, pred, 1, coll_tok, m3 ? ol3.f + c_cm : nullptr, ld3)) return -1;
+      if (msda_block(hb + LBM_W_HEAD_VIS, d->n_layers + 2, d->n_points, x, ref, 1, ta, m3 ? ol3.f + c_vis : nullptr, ld3)) return -1;
+      if (linear(ta, LBM_C, hb + LBM_W_HEAD_VISH_W0, hb + LBM_W_HEAD_VISH_B0, hidR, LBM_C, R, LBM_C, LBM_C, ACT_GELU)) return -1;
+      vis_hidden = hidR.f;
+    }
     StateFinalArgs f;
-    f.vis_hidden = hidR.f; f.w3 = W(hb + LBM_W_HEAD_VISH_W3); f.b3 = W(hb + LBM_W_HEAD_VISH_B3);
+    f.vis_hidden = vis_hidden; f.w3 = W(hb + LBM_W_HEAD_VISH_W3); f.b3 = W(hb + LBM_W_HEAD_VISH_B3);
     f.stream_tok = x.f; f.coll_tok = coll_tok.f; f.query_init = query; f.queried = d->queried ? d->queried + lo : nullptr;
     f.stream_out = d->stream_out ? d->stream_out + (long long)lo * LBM_C : nullptr;
     f.coll_out = d->coll_out ? d->coll_out + (long long)lo * LBM_C : nullptr;
@@ -749,6 +853,10 @@ int lbm_hip_debug_set(int32_t key, int32_t value) {
   }
   if (key == 15) {
     g_ffn_rows_mode = value;
+    return 0;
+  }
+  if (key == 17) {
+    g_head_pair = value;
     return 0;
   }
   if (key == 16) {

@@ -55,6 +55,10 @@ struct FfnDev {
   float* slabs;           // [1024 / CH][M, 256]
   long long slab_stride;
   int M;
+  int set_rows, nb0;      // two weight sets: rows of the first set and its 32-row blocks (0: one set)
+  const _Float16* F1b;
+  const float* b1b;
+  const _Float16* F2b;
 };
 
 constexpr int kC = 256, kHid = 1024, kRows = 32;
@@ -71,7 +75,14 @@ __global__ __launch_bounds__(256) void ffn_fused_kernel(FfnDev a) {
   __shared__ __attribute__((aligned(16))) _Float16 sH[NPL][kRows * HP];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int c = blockIdx.x, m0 = blockIdx.y * kRows;
+  const int c = blockIdx.x;
+  // two weight sets: the blocks of the second set start at row set_rows, each set ends at its own last row
+  const bool set2 = a.set_rows != 0 && (int)blockIdx.y >= a.nb0;
+  const int m0 = set2 ? a.set_rows + ((int)blockIdx.y - a.nb0) * kRows : blockIdx.y * kRows;
+  const int mend = (a.set_rows != 0 && !set2) ? a.set_rows : a.M;
+  const _Float16* F1 = set2 ? a.F1b : a.F1;
+  const _Float16* F2 = set2 ? a.F2b : a.F2;
+  const float* b1 = set2 ? a.b1b : a.b1;
   // CLAIM (lbm_hip_debug_set key 12 = 1; off by default): the wave claims the SIMD's whole register file (256 + 256), so no
   // wave of another kernel is resident beside it.  Round 1 shipped this as a guard: built with packed-fp32 instructions the
   // kernel came out with a few points perturbed at the 2^-11 level in ~1 frame of 20 of the frame pipeline.  The library is
@@ -84,7 +95,7 @@ __global__ __launch_bounds__(256) void ffn_fused_kernel(FfnDev a) {
 #pragma unroll
   for (int j = 0; j < NT1; ++j) {
     const int nb = c * (CH / 32) + w * NT1 + j;
-    const _Float16* p = a.F1 + ((long long)nb * KS1 * 2) * 512 + lane * 8;
+    const _Float16* p = F1 + ((long long)nb * KS1 * 2) * 512 + lane * 8;
 #pragma unroll
     for (int ks = 0; ks < KS1; ++ks) {
       b1h[j][ks] = *reinterpret_cast<const half8*>(p + (ks * 2) * 512);
@@ -98,7 +109,7 @@ __global__ __launch_bounds__(256) void ffn_fused_kernel(FfnDev a) {
     for (int it = 0; it < 4; ++it) {
       const int piece = it * 256 + tid;              // 32 rows x 32 pieces of 16 bytes
       const int row = piece >> 5, pc = piece & 31;
-      const int m = min(m0 + row, a.M - 1);
+      const int m = min(m0 + row, mend - 1);
       const half8 v = *reinterpret_cast<const half8*>(a.A + pl * a.a_plane + (long long)m * a.lda + pc * 8);
       *reinterpret_cast<half8*>(&sA[pl][row * kAP + pc * 8]) = v;
     }
@@ -106,7 +117,7 @@ __global__ __launch_bounds__(256) void ffn_fused_kernel(FfnDev a) {
   half8 b2h[2][KS2], b2l[2][KS2];
   auto fetch2 = [&](int j) {
     const int nb = w * 2 + j;
-    const _Float16* p = a.F2 + (((long long)nb * (kHid / 16) + c * KS2) * 2) * 512 + lane * 8;
+    const _Float16* p = F2 + (((long long)nb * (kHid / 16) + c * KS2) * 2) * 512 + lane * 8;
 #pragma unroll
     for (int ks = 0; ks < KS2; ++ks) {
       b2h[j][ks] = *reinterpret_cast<const half8*>(p + (ks * 2) * 512);
@@ -140,7 +151,7 @@ __global__ __launch_bounds__(256) void ffn_fused_kernel(FfnDev a) {
 #pragma unroll
   for (int j = 0; j < NT1; ++j) {
     const int cl = (w * NT1 + j) * 32 + r;          // hidden channel inside the chunk: this lane's accumulator column
-    const float bv = a.b1[c * CH + cl];
+    const float bv = b1[c * CH + cl];
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int rl = (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -180,7 +191,7 @@ __global__ __launch_bounds__(256) void ffn_fused_kernel(FfnDev a) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int row = m0 + (e & 3) + 8 * (e >> 2) + 4 * h;
-      if (row < a.M) out[(long long)row * kC + col] = NPL == 2 ? o[j][e] + ox[j][e] * (1.0f / 2048.0f) : o[j][e];
+      if (row < mend) out[(long long)row * kC + col] = NPL == 2 ? o[j][e] + ox[j][e] * (1.0f / 2048.0f) : o[j][e];
     }
   }
 #endif
@@ -389,6 +400,8 @@ int ffn_rows(const FfnArgs& f, hipStream_t stream) {
   FfnRowsDev d;
   d.f.A = (const _Float16*)f.A; d.f.a_plane = f.a_plane; d.f.lda = f.lda; d.f.F1 = (const _Float16*)f.F1; d.f.b1 = f.b1; d.f.F2 = (const _Float16*)f.F2;
   d.f.slabs = f.slabs; d.f.slab_stride = f.slab_stride; d.f.M = f.M;
+  d.f.set_rows = 0; d.f.nb0 = 0; d.f.F1b = nullptr; d.f.b1b = nullptr; d.f.F2b = nullptr;
+  LBM_REQUIRE(f.set_rows == 0, "ffn_rows: two weight sets are a feature of the few-rows kernel");
   d.dbg = g_ffn_rows_dbg;
   d.steps_total = (f.M + kRows - 1) / kRows;
   int groups = std::min(d.steps_total, 32);             // 8 chunks x 32 row ranges = one workgroup per CU
@@ -415,7 +428,16 @@ int ffn_fused(const FfnArgs& f, hipStream_t stream) {
   FfnDev d;
   d.A = (const _Float16*)f.A; d.a_plane = f.a_plane; d.lda = f.lda; d.F1 = (const _Float16*)f.F1; d.b1 = f.b1; d.F2 = (const _Float16*)f.F2;
   d.slabs = f.slabs; d.slab_stride = f.slab_stride; d.M = f.M;
-  const dim3 grid(kHid / f.chunk, (f.M + kRows - 1) / kRows);
+  d.set_rows = 0; d.nb0 = 0; d.F1b = nullptr; d.b1b = nullptr; d.F2b = nullptr;
+  int nblk = (f.M + kRows - 1) / kRows;
+  if (f.set_rows > 0) {
+    LBM_REQUIRE(f.set_rows < f.M && f.F1b && f.b1b && f.F2b && ((uintptr_t)f.F1b & 15) == 0 && ((uintptr_t)f.F2b & 15) == 0,
+                "ffn_fused: a two-set launch needs the second weight set and 0 < set_rows < M");
+    d.set_rows = f.set_rows; d.nb0 = (f.set_rows + kRows - 1) / kRows;
+    d.F1b = (const _Float16*)f.F1b; d.b1b = f.b1b; d.F2b = (const _Float16*)f.F2b;
+    nblk = d.nb0 + (f.M - f.set_rows + kRows - 1) / kRows;
+  }
+  const dim3 grid(kHid / f.chunk, nblk);
   const double flops = 4.0 * f.M * kC * kHid;
   const double bytes = 2.0 * f.planes * (f.M * kC + 2.0 * kC * kHid) + 4.0 * f.M * kC * (kHid / f.chunk);
   ProfScope prof(f.planes == 2 ? "ffn_fused_ss" : "ffn_fused_sh", stream, flops, bytes);

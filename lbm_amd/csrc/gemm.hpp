@@ -120,6 +120,11 @@ struct FfnArgs {
   float* slabs = nullptr;         // [1024 / chunk][M, 256] partial outputs (no bias)
   long long slab_stride = 0;
   int M = 0, chunk = 128, planes = 2;
+  // two weight sets in one launch (few-rows kernel): rows [0, set_rows) use F1 / b1 / F2, rows [set_rows, M) the second set
+  int set_rows = 0;               // 0: one set
+  const void* F1b = nullptr;
+  const float* b1b = nullptr;
+  const void* F2b = nullptr;
 };
 int ffn_fused(const FfnArgs& f, hipStream_t stream);
 int ffn_rows(const FfnArgs& f, hipStream_t stream);     // the same slabs for many rows: weights stationary, rows streamed (ffn.hip)

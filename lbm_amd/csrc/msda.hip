@@ -26,7 +26,9 @@ __global__ __launch_bounds__(256) void msda_sample_kernel(MsdaArgs a) {
   __shared__ float sm[LBM_HEADS][3][64];
   const int lane = threadIdx.x & 63;
   const int hd = threadIdx.x >> 6;
-  const long long r = blockIdx.x;
+  const long long rq = blockIdx.x;                                   // output row
+  const int set = (a.set_rows != 0 && rq >= a.set_rows) ? 1 : 0;     // second module of a two-module launch (workgroup-uniform)
+  const long long r = rq - (long long)set * a.set_rows;               // the point this row belongs to
   const int b = (int)(r / a.N);
   const int P = PT ? PT : a.P;
   const int S = LBM_LEVELS * P;
@@ -35,7 +37,7 @@ __global__ __launch_bounds__(256) void msda_sample_kernel(MsdaArgs a) {
   float dx = 0.f, dy = 0.f, wt = 0.f;
   if (EXPLICIT) {
     if (lane < S) {
-      const long long idx = (r * LBM_HEADS + hd) * S + lane;
+      const long long idx = (rq * LBM_HEADS + hd) * S + lane;
       dx = a.loc[idx * 2];
       dy = a.loc[idx * 2 + 1];
       wt = a.attw[idx];
@@ -44,7 +46,7 @@ __global__ __launch_bounds__(256) void msda_sample_kernel(MsdaArgs a) {
     float logit = -INFINITY;
     if (lane < S) {
       const int l = lane / P;
-      const float* o = a.offlog + r * a.ld_offlog;
+      const float* o = a.offlog + r * a.ld_offlog + set * a.set_offlog_off;
       const int oi = (hd * S + lane) * 2;
       dx = o[oi] / (float)sel4(a.lvl_w, l);        // msdeformattn.py:161-165 (offset / (w_l, h_l))
       dy = o[oi + 1] / (float)sel4(a.lvl_h, l);
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(256) void msda_sample_kernel(MsdaArgs a) {
 
   // ---- stage 2: gather ----
   const int tap = lane >> 4, tx = tap & 1, ty = tap >> 1, cq = lane & 15;
-  const float* vb = a.value + (long long)b * a.v_batch_stride + hd * LBM_HD + cq * 4;
+  const float* vb = a.value + (long long)b * a.v_batch_stride + set * a.set_value_off + hd * LBM_HD + cq * 4;
   {
     const int kk = blockIdx.y;
     float rx = 0.f, ry = 0.f;
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(256) void msda_sample_kernel(MsdaArgs a) {
     acc.x += __shfl_xor(acc.x, 16); acc.y += __shfl_xor(acc.y, 16); acc.z += __shfl_xor(acc.z, 16); acc.w += __shfl_xor(acc.w, 16);
     acc.x += __shfl_xor(acc.x, 32); acc.y += __shfl_xor(acc.y, 32); acc.z += __shfl_xor(acc.z, 32); acc.w += __shfl_xor(acc.w, 32);
     if (lane < 16) {
-      const long long oo = (r * a.k + kk) * LBM_C + hd * LBM_HD + cq * 4;
+      const long long oo = (rq * a.k + kk) * LBM_C + hd * LBM_HD + cq * 4;
       if (a.out) st4(a.out + oo, acc);
       if (a.out_s) st4_split(a.out_s, a.out_plane, oo, acc);
     }
@@ -125,8 +127,8 @@ int msda_sample(const MsdaArgs& a, hipStream_t stream) {
   const bool explicit_mode = a.loc != nullptr;
   // algorithmic traffic per query: 4 heads x 4 levels x P points x 4 taps x 64 channels read (L2/MALL-resident maps),
   // one 256-channel row written
-  ProfScope prof("msda_sample", stream, (double)R * a.k * 16.0 * a.P * 4 * 64 * 2,
-                 (double)R * a.k * (16.0 * a.P * 4 * 64 * 4 + 4.0 * LBM_C));
+  const double nq = (double)R * a.k * (a.set_rows ? 2 : 1);
+  ProfScope prof("msda_sample", stream, nq * 16.0 * a.P * 4 * 64 * 2, nq * (16.0 * a.P * 4 * 64 * 4 + 4.0 * LBM_C));
   if (explicit_mode) {
     LBM_REQUIRE(a.attw != nullptr && a.k == 1, "msda_sample: explicit mode needs attw and k == 1");
     hipLaunchKernelGGL((msda_sample_kernel<true, 0>), dim3((unsigned)R, 1), dim3(256), 0, stream, a);
@@ -134,7 +136,8 @@ int msda_sample(const MsdaArgs& a, hipStream_t stream) {
     LBM_REQUIRE(a.offlog && a.ref && a.net_w > 0.f && a.net_h > 0.f, "msda_sample: implicit mode needs offlog/ref/net size");
     LBM_REQUIRE(a.ld_offlog >= a.logit_col + 16 * a.P && a.logit_col >= 32 * a.P, "msda_sample: offlog layout too small");
     LBM_REQUIRE(a.k <= 65535, "msda_sample: k=%d too large", a.k);
-    const dim3 grid((unsigned)R, (unsigned)a.k);
+    LBM_REQUIRE(a.set_rows == 0 || a.set_rows == R, "msda_sample: a two-module launch covers every point twice (set_rows == B * N)");
+    const dim3 grid((unsigned)(a.set_rows ? 2 * R : R), (unsigned)a.k);
     if (a.P == 9) hipLaunchKernelGGL((msda_sample_kernel<false, 9>), grid, dim3(256), 0, stream, a);
     else if (a.P == 4) hipLaunchKernelGGL((msda_sample_kernel<false, 4>), grid, dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((msda_sample_kernel<false, 0>), grid, dim3(256), 0, stream, a);

@@ -27,6 +27,10 @@ struct MsdaArgs {
   float* out = nullptr;           // [R*k, 256]
   void* out_s = nullptr;          // the same as split f16 planes (lo plane out_plane elements after hi); either may be null
   long long out_plane = 0;
+  // --- two modules in one launch (implicit mode): rows [0, set_rows) use the pointers above, rows [set_rows, 2 set_rows) the SAME
+  // points and reference cells with another value map and another column block of offlog (element offsets below) ---
+  int set_rows = 0;               // 0: one module
+  long long set_value_off = 0, set_offlog_off = 0;
 };
 
 int msda_sample(const MsdaArgs& a, hipStream_t stream);

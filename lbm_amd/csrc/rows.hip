@@ -30,9 +30,13 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(RowsIn in, const fl
 #pragma unroll
   for (int sl = 1; sl < NS; ++sl) ps[sl - 1] = ld4(X + sl * in.slab_stride + off);
   const bool has_bias = in.bias != nullptr, has_res = in.res != nullptr;
-  const float4 pb = ld4((has_bias ? in.bias : gamma) + lane * 4);
-  const float4 pr = ld4(has_res ? in.res + (long long)(row / in.res_div) * LBM_C + lane * 4 : gamma + lane * 4);
-  const float4 g = ld4(gamma + lane * 4), b = ld4(beta + lane * 4);
+  const bool set2 = in.set_rows != 0 && row >= in.set_rows;            // wave-uniform: a wave owns one row
+  const float* gam = set2 ? in.gamma2 : gamma;
+  const float* bet = set2 ? in.beta2 : beta;
+  const int rrow = set2 ? row - in.set_rows : row;
+  const float4 pb = ld4((has_bias ? (set2 ? in.bias2 : in.bias) : gam) + lane * 4);
+  const float4 pr = ld4(has_res ? (set2 ? in.res2 : in.res) + (long long)(rrow / in.res_div) * LBM_C + lane * 4 : gam + lane * 4);
+  const float4 g = ld4(gam + lane * 4), b = ld4(bet + lane * 4);
   float4 y;
   if (kb == 0) {
     y = ld4(fallback + off);
@@ -137,6 +141,8 @@ int layernorm_rows_in(const RowsIn& in, const float* gamma, const float* beta, i
   LBM_REQUIRE(in.X && gamma && beta && (out.Y || out.Ys) && rows > 0, "layernorm_rows: null argument");
   LBM_REQUIRE(in.nslab >= 1 && in.res_div >= 1, "layernorm_rows: bad input description");
   LBM_REQUIRE(keep == nullptr || fallback != nullptr, "layernorm_rows: keep mask needs a fallback");
+  LBM_REQUIRE(in.set_rows == 0 || (in.gamma2 && in.beta2 && (in.bias == nullptr || in.bias2) && (in.res == nullptr || in.res2) && !g_ln_serial && keep == nullptr),
+              "layernorm_rows: a two-set launch needs the second gamma / beta / bias and no keep mask");
   const int nout = (out.Y ? 1 : 0) + (out.Ys ? 1 : 0) + (out.Yn ? 1 : 0) + (out.Yns ? 1 : 0);
   ProfScope prof("layernorm_rows", stream, 0.0, 4.0 * LBM_C * rows * (in.nslab + (in.res ? 1.0 / in.res_div : 0.0) + nout));
   const dim3 grid((rows + 3) / 4);

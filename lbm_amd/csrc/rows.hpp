@@ -31,6 +31,12 @@ struct RowsIn {
   const float* res = nullptr;    // [rows / res_div, 256] or null
   int res_div = 1;
   float res_scale = 1.f;
+  // two parameter sets in one launch: rows [set_rows, ...) take bias2 / gamma2 / beta2 / res2
+  int set_rows = 0;              // 0: one set
+  const float* bias2 = nullptr;
+  const float* res2 = nullptr;   // residual of the second set, indexed by (row - set_rows) / res_div
+  const float* gamma2 = nullptr;
+  const float* beta2 = nullptr;
 };
 int layernorm_rows_in(const RowsIn& in, const float* gamma, const float* beta, int rows, const uint8_t* keep,
                       const float* fallback, const RowsOut& out, hipStream_t stream);

@@ -843,6 +843,36 @@ def test_correlation_product_with_fused_top_k_selects_the_same_cells(hip):
             assert torch.equal(a[i], b[i]), name
 
 
+def test_offset_and_visibility_heads_as_one_pair_are_bit_identical_to_two_chains(hip):
+    """debug key 17: 1 (default) runs the offset and the visibility head as one batch of two parameter sets through every launch
+    (sampling, projection, LayerNorm, feed-forward, LayerNorm, first MLP layer), 0 as two separate chains.  Same arithmetic per
+    row, so every output of the step must agree bit for bit."""
+    g = fx.geometry("full256")
+    tr, _ = _transformer(g, precision="split")
+    lib = hip.load()
+    for B, N, seed in ((1, 300, 81), (2, 257, 82)):
+        cu = {k: v.cuda() for k, v in fx.step_inputs(g, B, N, seed=seed).items()}
+        outs = {}
+        try:
+            for mode in (0, 1):
+                lib.lbm_hip_debug_set(17, mode)
+                with torch.no_grad():      # (the first call of a configuration also packs weights / builds per-query caches)
+                    tr(cu["query"], cu["feat"], cu["stream"], cu["collision"], cu["vis_mask"], cu["mem_mask"], cu["queried"])
+                hip.profile_begin()
+                with torch.no_grad():
+                    outs[mode] = tr(cu["query"], cu["feat"], cu["stream"], cu["collision"], cu["vis_mask"], cu["mem_mask"], cu["queried"])
+                launches = sum(p["launches"] for p in hip.profile_end())
+                outs[mode] = (outs[mode], launches)
+        finally:
+            lib.lbm_hip_debug_set(17, 1)
+        (a, na), (b, nb) = outs[0], outs[1]
+        assert nb == na - 6, (na, nb)                      # the pair saves six launches
+        for i in (2, 3, 4):
+            assert torch.equal(a[i], b[i]), (B, N, i)
+        for key in a[1]:
+            assert torch.equal(a[1][key], b[1][key]), (B, N, key)
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # reduced-precision mode (precision "f16": plain f16 operands on the matrix cores, fp32 accumulate; SURVEY 8's
 # "bf16 storage / fp32 accumulate" class, bar 1e-2 on logits)

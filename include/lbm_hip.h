@@ -394,7 +394,18 @@ typedef struct {
 int lbm_hip_profile_begin(void);
 int lbm_hip_profile_end(lbm_hip_profile_entry* out, int32_t cap);
 
-/* tuning / debugging knob (process-wide): key 1 = force the split-GEMM tiling (0 auto, 1..n see gemm16.hip) */
+/* tuning / debugging knobs (process-wide; 0 restores the default unless noted).  None changes results beyond the last bit except
+ * the reproducer variants of key 9 and the ablation bits of keys 14 / 16 (timing only).
+ *   1  force the split-GEMM tiling (1..23, gemm16.hip)          2  split-GEMM flags (256 = never / 512 = always the row-streaming
+ *   3  attention read-out mode                                      kernel, 32 = no XCD remap, bits 12.. = its ablation switches)
+ *   4  force the convolution tiling (1..14)                     5  dense top-k mode
+ *   6  largest k fused into the tiled correlation product below 4096 rows (default 1)
+ *   7  most rows for the few-rows fused feed-forward (default 2048)   8  feed-forward sites that may fuse (bit mask, default 63)
+ *   9  correlation-map kernel variant (0 product, 6 cell-by-cell, 1..4 packed-fp32 reproducers)
+ *  10  corr_maps uses the caller's inv_norm as it is             11  serial-load LayerNorm      12  fused feed-forward claims the register file
+ *  13  correlation + top-k by the row-streaming kernel (default 1)   14  its ablation bits
+ *  15  many-rows fused feed-forward: 0 auto (above key 7's row count), 1 never, 2 always        16  its ablation bits
+ *  17  offset and visibility heads as one batch of two (default 1)                                                              */
 int lbm_hip_debug_set(int32_t key, int32_t value);
 /* the same for pointer-valued knobs: key 1 = device buffer (768 floats per 2x2 cell block) that correlation-map variant 2
  * (debug key 9 = 2) fills with what each wave loaded and computed -- reproduction aid; NULL = off */

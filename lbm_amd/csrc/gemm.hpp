@@ -106,6 +106,9 @@ struct ConvSSArgs {
   int planes = 2;                 // as GemmSSArgs::planes
 };
 int conv2d_nhwc_ss(const ConvSSArgs& c, hipStream_t stream);
+// 3 x 3 / stride 1 / 64 -> 64 channels over many pixels: weights stationary, image patches streamed (conv_rs.hip); bit-identical
+bool conv64_rows_ok(const ConvSSArgs& c);
+int conv64_rows(const ConvSSArgs& c, hipStream_t stream);
 int maxpool3x3s2_nhwc(const float* x, float* y, int B, int H, int W, int C, hipStream_t stream, void* ys = nullptr,
                       long long ys_plane = 0);
 

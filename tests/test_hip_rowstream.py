@@ -139,3 +139,32 @@ def test_many_rows_feed_forward_leaves_the_same_slabs_as_the_few_rows_kernel(hip
     assert torch.equal(a.view(torch.int32), b.view(torch.int32))
     want = torch.nn.functional.gelu(x.double() @ W1.double().t() + b1.double()) @ W2.double().t()
     assert float((b.sum(0).double() - want).abs().max()) < 2e-5 * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 5, 32), (2, 24, 64), (3, 7, 96), (4, 96, 128)])
+@pytest.mark.parametrize("relu,use_res,f32,split", [(True, False, False, True), (True, True, True, True), (False, False, True, False)])
+def test_patch_streaming_convolution_is_bit_identical_to_the_tiled_one(hip, B, H, W, relu, use_res, f32, split):
+    """conv64_rows_kernel (3 x 3, stride 1, 64 -> 64; debug key 4 = 16) against the tiled implicit GEMM (key 4 = 15): same accumulation
+    chain, so every output must agree bit for bit -- borders (zero padding), one-row images and every output combination included."""
+    lib = hip.load()
+    g = torch.Generator(device="cpu").manual_seed(B * 100 + H)
+    x = torch.randn(B, H, W, 64, generator=g).cuda()
+    w = hip.SplitWeight((torch.randn(64, 576, generator=g) * 0.05).cuda())
+    b = torch.randn(64, generator=g).cuda()
+    res = torch.randn(B, H, W, 64, generator=g).cuda() if use_res else None
+    xs = _split(hip, x)
+    outs = {}
+    try:
+        for mode in (15, 16):
+            lib.lbm_hip_debug_set(4, mode)
+            hip.profile_begin()
+            outs[mode] = hip.conv2d_nhwc_ss(xs, w, b, 3, 1, 1, relu, res, f32, split)
+            names = {p["name"] for p in hip.profile_end()}
+            assert ("conv64_rows" in names) == (mode == 16), names
+    finally:
+        lib.lbm_hip_debug_set(4, 0)
+    (y0, s0), (y1, s1) = outs[15], outs[16]
+    if f32:
+        assert torch.equal(y0.view(torch.int32), y1.view(torch.int32))
+    if split:
+        assert torch.equal(s0.planes.view(torch.int16), s1.planes.view(torch.int16))

@@ -5,15 +5,17 @@
 // the IMAGE streams through: a step is 32 consecutive output pixels of one image row, its input is the 3 x 34 pixel patch around
 // them (30 KB with padding, fetched once), and the nine taps read their operand fragments straight out of that patch in LDS.
 //
-// Workgroup = 4 waves (one per SIMD): wave (kh, cb) owns output columns [32 cb, 32 cb + 32) and half kh of the K = 576 extent (18 of
+// Workgroup = 8 waves.  Four multiply (one per SIMD): wave (kh, cb) owns output columns [32 cb, 32 cb + 32) and half kh of the K = 576 extent (18 of
 // the 36 k-steps: 144 VGPRs of weight fragments).  The two halves of a column block form a chain so that the accumulation ORDER is the
 // tiled kernel's (results bit-identical): wave (0, cb) multiplies k-steps 0..17 of step j and hands its two accumulators over through
 // LDS; wave (1, cb) picks them up one step later, adds k-steps 18..35 and runs the epilogue (bias, residual, ReLU, fp32 / split
-// output, transposed through the hand-over buffer it has just emptied).  Only the (0, .) waves issue LDS-DMA (hand-counted vmcnt);
-// the (1, .) waves have only ordinary loads / stores, which the compiler's own waits handle.  Patches live in a ring of 4 stages
-// (step j is read in iterations j and j + 1, steps j + 1 and j + 2 are in flight); one barrier per step.
+// output) is NOT theirs: four helper waves share the SIMDs with them -- two issue the LDS-DMA of the patches (hand-counted vmcnt, no
+// other memory traffic in those waves), two take the finished 32 x 32 blocks from LDS one more step later and do bias-free residual /
+// ReLU / output stores (ordinary loads and stores, compiler-managed waits) -- so address arithmetic, DMA issue and stores sit in the
+// issue slots the MFMAs leave free.  Patches live in a ring of 4 stages (step j is read in iterations j and j + 1, steps j + 1 and
+// j + 2 are in flight); one barrier per step.
 //
-// Patch image in LDS: [ky 0..2][plane][pixel 0..39][64 channels] f16, a pixel = 128 B = eight 16-byte slots, slot s of pixel p stored at
+// Patch image in LDS: [ky 0..2][plane][pixel 0..33][64 channels] f16, a pixel = 128 B = eight 16-byte slots, slot s of pixel p stored at
 // s ^ ((p >> 1) & 7): the 16 lanes of a ds_read_b128 group read 16 consecutive pixels -> 16 different (p & 1, (p >> 1) & 7) -> no
 // bank conflict.  The swizzle is applied on the source side of the DMA (the LDS side is lane-linear).
 #include "gemm.hpp"
@@ -22,6 +24,8 @@
 #include <type_traits>
 
 namespace lbm {
+
+int g_conv64_dbg = 0;   // debug key 18
 
 struct Conv64Dev {
   const _Float16* X;
@@ -37,164 +41,196 @@ struct Conv64Dev {
   const _Float16* zeros;
   int B, H, W, relu;
   int steps_total, spg;
+  int dbg;   // tuning (timing only): 1 no DMA after the prologue, 2 no epilogue, 4 no producer MFMAs, 8 no consumer MFMAs
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_c64;
 
-__global__ __launch_bounds__(256) void conv64_rows_kernel(Conv64Dev a) {
+static __device__ __align__(256) unsigned char g_zero_row[34 * 128];      // what rows above / below the image and pixels -1 / W read (never written)
+
+__global__ __launch_bounds__(512) void conv64_rows_kernel(Conv64Dev a) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int ROWB = 40 * 128;            // bytes of one (ky, plane) pixel row of the patch
-  constexpr int PATCH = 6 * ROWB;           // 30720
+  constexpr int ROWB = 34 * 128;            // bytes of one (ky, plane) pixel row of the patch: 34 pixels, no padding
+  constexpr int PATCH = 6 * ROWB;           // 26112
   constexpr int NST = 4;
   constexpr int HAND = 8192;                // one wave's two accumulators
-  constexpr int OFF_HAND = NST * PATCH;     // [2 buffers][2 column blocks][HAND]
-  constexpr int OFF_DUMP = OFF_HAND + 4 * HAND;
   constexpr int TP = 36;
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[OFF_DUMP + 1024];
+  constexpr int FIN = 32 * TP * 4;          // one wave's finished 32 x 32 block, row-major with pitch TP
+  constexpr int OFF_HAND = NST * PATCH;     // [2 buffers][2 column blocks][HAND]
+  constexpr int OFF_FIN = OFF_HAND + 4 * HAND;   // [2 buffers][2 column blocks][FIN]
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[OFF_FIN + 4 * FIN];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int kh = wave >> 1, cb = wave & 1;
+  const int role = wave >> 1, cb = wave & 1;          // 0 first half of K, 1 second half, 2 DMA, 3 epilogue; waves w and w + 4 share a SIMD
   const int r = lane & 31, h = lane >> 5;
   const int s0 = blockIdx.x * a.spg;
   const int ns = min(a.spg, a.steps_total - s0);
   if (ns <= 0) return;
   const int spr = a.W >> 5;                 // steps per image row
 
-  // ---- this wave's half of the weights as MFMA B-fragments: lane (r, h) = output column 32 cb + r, k = 16 ks + 8 h .. + 8 ----
-  half8 wh[18], wl[18];
-  {
-    const long long wo = (long long)(cb * 32 + r) * a.ldw + kh * 288 + 8 * h;
-#pragma unroll
-    for (int i = 0; i < 18; ++i) {
-      wh[i] = *reinterpret_cast<const half8*>(a.Wh + wo + i * 16);
-      wl[i] = *reinterpret_cast<const half8*>(a.Wl + wo + i * 16);
-    }
-  }
-  // fragment byte offsets inside a (ky, plane) row for tap column kx and channel quarter q: pixel r + kx, slot (2 q + h) ^ swizzle
-  int foff[3][4];
-#pragma unroll
-  for (int kx = 0; kx < 3; ++kx) {
-    const int p = r + kx, sw = (p >> 1) & 7;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) foff[kx][q] = p * 128 + (((2 * q + h) ^ sw) << 4);
-  }
-
   auto handover = [&]() __attribute__((always_inline)) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
-  // k-steps [18 kh, 18 kh + 18) of the patch at Pb, fragments of the next pair of k-steps requested before this pair's MFMAs
-  f32x16 acc, acx;
-  auto mac = [&](const unsigned char* Pb, auto khc) __attribute__((always_inline)) {
-    constexpr int KH = decltype(khc)::value;          // compile-time half: taps and channel quarters of every k-step are constants
-    half8 fa[2][4];
-    auto ldg = [&](const int bsel, const int g) __attribute__((always_inline)) {
-#pragma unroll
-      for (int qq = 0; qq < 2; ++qq) {
-        const int ks = 18 * KH + 2 * g + qq;
-        const int tap = ks >> 2, q = ks & 3;
-        const int ky = tap / 3, kx = tap - 3 * ky;
-        const unsigned char* p = Pb + (ky * 2) * ROWB + foff[kx][q];
-        fa[bsel][2 * qq] = *reinterpret_cast<const half8*>(p);
-        fa[bsel][2 * qq + 1] = *reinterpret_cast<const half8*>(p + ROWB);
-      }
-    };
-    ldg(0, 0);
-#pragma unroll
-    for (int g = 0; g < 9; ++g) {
-      if (g + 1 < 9) ldg((g + 1) & 1, g + 1);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int qq = 0; qq < 2; ++qq) {
-        const int i = 2 * g + qq;
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[g & 1][2 * qq], wh[i], acc, 0, 0, 0);
-        acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[g & 1][2 * qq], wl[i], acx, 0, 0, 0);
-        acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[g & 1][2 * qq + 1], wh[i], acx, 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
 
-  if (kh == 0) {
-    // ---- producer of the chain: DMA of the patches + the first half of K ----
-    auto issue = [&](const int j) __attribute__((always_inline)) {
-      const int g = s0 + j;
-      const int row = g / spr, ox0 = (g - row * spr) << 5;
-      const int b = row / a.H, oy = row - b * a.H;
-      unsigned char* stage = lds + (j & (NST - 1)) * PATCH;
+  if (role < 2) {
+    const int kh = role;
+    // ---- this wave's half of the weights as MFMA B-fragments: lane (r, h) = output column 32 cb + r, k = 16 ks + 8 h .. + 8 ----
+    half8 wh[18], wl[18];
+    {
+      const long long wo = (long long)(cb * 32 + r) * a.ldw + kh * 288 + 8 * h;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int pid = cb * 16 + i;                 // 30 real pieces, 2 dummies that keep the count per wave even
-        const int ky = pid / 10, pl = (pid / 5) & 1, seg = pid % 5;
-        const int pq = seg * 8 + (lane >> 3);        // patch pixel of this lane
-        const int slot = (lane & 7) ^ ((pq >> 1) & 7);
-        const int y = oy - 1 + ky, x = ox0 - 1 + pq;
-        const bool ok = pid < 30 && pq < 34 && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
-        const _Float16* src = ok ? a.X + pl * a.x_plane + (((long long)b * a.H + y) * a.W + x) * 64 + slot * 8 : a.zeros;
-        unsigned char* dst = pid < 30 ? stage + ((ky * 2 + pl) * 40 + seg * 8) * 128 : lds + OFF_DUMP;
-        __builtin_amdgcn_global_load_lds(src, (lds_ptr_c64)dst, 16, 0, 0);
-      }
-    };
-    issue(0);
-    if (ns > 1) issue(1);
-    __builtin_amdgcn_s_waitcnt(0x0F70);            // the weight fragments are in (a wait the compiler can see); so are patches 0 and 1
-    for (int k = 0; k <= ns; ++k) {
-      if (k + 1 < ns && k > 0) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // patch k landed, patch k + 1 may be in flight
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      handover();
-      if (k >= ns) break;
-      if (k + 2 < ns) issue(k + 2);                // stage of patch k - 2: last read in iteration k - 1
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[e] = acx[e] = 0.f;
-      mac(lds + (k & (NST - 1)) * PATCH, std::integral_constant<int, 0>{});
-      // hand both accumulators to the consumer of this column block
-      f32x4* hb = reinterpret_cast<f32x4*>(lds + OFF_HAND + ((k & 1) * 2 + cb) * HAND) + lane;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        hb[i * 64] = f32x4{acc[4 * i], acc[4 * i + 1], acc[4 * i + 2], acc[4 * i + 3]};
-        hb[(4 + i) * 64] = f32x4{acx[4 * i], acx[4 * i + 1], acx[4 * i + 2], acx[4 * i + 3]};
+      for (int i = 0; i < 18; ++i) {
+        wh[i] = *reinterpret_cast<const half8*>(a.Wh + wo + i * 16);
+        wl[i] = *reinterpret_cast<const half8*>(a.Wl + wo + i * 16);
       }
     }
-  } else {
-    // ---- consumer: second half of K, epilogue ----
-    const int col = cb * 32 + r;
-    const float bv = a.bias ? a.bias[col] : 0.f;
-    for (int k = 0; k <= ns; ++k) {
-      handover();
-      if (k == 0) continue;
-      const int j = k - 1;
-      unsigned char* hbuf = lds + OFF_HAND + ((j & 1) * 2 + cb) * HAND;
-      {
-        const f32x4* hb = reinterpret_cast<const f32x4*>(hbuf) + lane;
+    // fragment byte offsets inside a (ky, plane) row for tap column kx and channel quarter q: pixel r + kx, slot (2 q + h) ^ swizzle
+    int foff[3][4];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int p = r + kx, sw = (p >> 1) & 7;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) foff[kx][q] = p * 128 + (((2 * q + h) ^ sw) << 4);
+    }
+    // k-steps [18 KH, 18 KH + 18) of the patch at Pb, fragments of the next pair of k-steps requested before this pair's MFMAs
+    f32x16 acc, acx;
+    auto mac = [&](const unsigned char* Pb, auto khc) __attribute__((always_inline)) {
+      constexpr int KH = decltype(khc)::value;          // compile-time half: taps and channel quarters of every k-step are constants
+      half8 fa[2][4];
+      auto ldg = [&](const int bsel, const int g) __attribute__((always_inline)) {
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+          const int ks = 18 * KH + 2 * g + qq;
+          const int tap = ks >> 2, q = ks & 3;
+          const int ky = tap / 3, kx = tap - 3 * ky;
+          const unsigned char* p = Pb + (ky * 2) * ROWB + foff[kx][q];
+          fa[bsel][2 * qq] = *reinterpret_cast<const half8*>(p);
+          fa[bsel][2 * qq + 1] = *reinterpret_cast<const half8*>(p + ROWB);
+        }
+      };
+      ldg(0, 0);
+#pragma unroll
+      for (int g = 0; g < 9; ++g) {
+        if (g + 1 < 9) ldg((g + 1) & 1, g + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+          const int i = 2 * g + qq;
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[g & 1][2 * qq], wh[i], acc, 0, 0, 0);
+          acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[g & 1][2 * qq], wl[i], acx, 0, 0, 0);
+          acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[g & 1][2 * qq + 1], wh[i], acx, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    if (kh == 0) {
+      // ---- first half of K for step k, accumulators handed to the second half through LDS ----
+      for (int k = 0; k <= ns + 1; ++k) {
+        handover();
+        if (k >= ns) continue;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = acx[e] = 0.f;
+        if (!(a.dbg & 4)) mac(lds + (k & (NST - 1)) * PATCH, std::integral_constant<int, 0>{});
+        f32x4* hb = reinterpret_cast<f32x4*>(lds + OFF_HAND + ((k & 1) * 2 + cb) * HAND) + lane;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          hb[i * 64] = f32x4{acc[4 * i], acc[4 * i + 1], acc[4 * i + 2], acc[4 * i + 3]};
+          hb[(4 + i) * 64] = f32x4{acx[4 * i], acx[4 * i + 1], acx[4 * i + 2], acx[4 * i + 3]};
+        }
+      }
+    } else {
+      // ---- second half of K for step k - 1; the finished block goes to the epilogue wave, row-major, bias added ----
+      const float bv = a.bias ? a.bias[cb * 32 + r] : 0.f;
+      for (int k = 0; k <= ns + 1; ++k) {
+        handover();
+        if (k == 0 || k > ns) continue;
+        const int j = k - 1;
+        const f32x4* hb = reinterpret_cast<const f32x4*>(lds + OFF_HAND + ((j & 1) * 2 + cb) * HAND) + lane;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const f32x4 u = hb[i * 64], v = hb[(4 + i) * 64];
           acc[4 * i] = u[0]; acc[4 * i + 1] = u[1]; acc[4 * i + 2] = u[2]; acc[4 * i + 3] = u[3];
           acx[4 * i] = v[0]; acx[4 * i + 1] = v[1]; acx[4 * i + 2] = v[2]; acx[4 * i + 3] = v[3];
         }
-      }
-      mac(lds + (j & (NST - 1)) * PATCH, std::integral_constant<int, 1>{});
-      // transpose the 32 x 32 block through the (now empty) hand-over buffer and write 16-byte row pieces
-      float* Tw = reinterpret_cast<float*>(hbuf);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (!(a.dbg & 8)) mac(lds + (j & (NST - 1)) * PATCH, std::integral_constant<int, 1>{});
+        float* Tw = reinterpret_cast<float*>(lds + OFF_FIN + ((j & 1) * 2 + cb) * FIN);
 #pragma unroll
-      for (int e = 0; e < 16; ++e) Tw[(4 * h + (e & 3) + 8 * (e >> 2)) * TP + r] = (acc[e] + acx[e] * (1.0f / 2048.0f)) + bv;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      const int g = s0 + j;
-      const int row = g / spr, ox0 = (g - row * spr) << 5;
-      const long long m0 = (long long)row * a.W + ox0;     // (row = b * H + oy: NHWC pixels are row-major over (b, y, x))
+        for (int e = 0; e < 16; ++e) Tw[(4 * h + (e & 3) + 8 * (e >> 2)) * TP + r] = (acc[e] + acx[e] * (1.0f / 2048.0f)) + bv;
+      }
+    }
+  } else if (role == 2) {
+    // ---- DMA: the patch of step k + 2.  Wave cb fetches plane cb: 3 rows x 5 pieces of 8 pixels (the fifth piece of a row holds
+    // pixels 32 and 33 only: its other lanes are switched off, the next row starts right behind).  Everything per lane is constant
+    // over the steps (byte offset of its 16-byte slot from the row's pixel -1); everything that changes is uniform (the row's base
+    // address, or the zero row for a row above / below the image) -- two vector instructions per piece instead of an address
+    // computation, since these waves share their SIMDs' issue slots with the multiplying waves.
+    int voff[5];
+#pragma unroll
+    for (int seg = 0; seg < 5; ++seg) {
+      const int pq = seg * 8 + (lane >> 3);
+      voff[seg] = pq * 64 + (((lane & 7) ^ ((pq >> 1) & 7)) << 3);      // in f16 elements
+    }
+    const _Float16* zrow = reinterpret_cast<const _Float16*>(g_zero_row);
+    const _Float16* Xp = a.X + cb * a.x_plane;
+    // raster position of the next step to issue
+    int ib, iy, ix;
+    {
+      const int row = s0 / spr;
+      ix = (s0 - row * spr) << 5;
+      ib = row / a.H; iy = row - ib * a.H;
+    }
+    auto issue = [&](const int j) __attribute__((always_inline)) {
+      unsigned char* stage = lds + (j & (NST - 1)) * PATCH + cb * ROWB;
+      const bool eL = ix == 0, eR = ix + 32 == a.W;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int y = iy - 1 + ky;
+        const _Float16* rb = (unsigned)y < (unsigned)a.H ? Xp + (((long long)ib * a.H + y) * a.W + ix - 1) * 64 : zrow;
+#pragma unroll
+        for (int seg = 0; seg < 5; ++seg) {
+          const _Float16* src = rb + voff[seg];
+          if (seg == 0 && eL && lane < 8) src = zrow + voff[0];                   // pixel -1 of the image row
+          if (seg == 4 && eR && (lane >> 3) == 1) src = zrow + voff[4];           // pixel W
+          unsigned char* dst = stage + ky * 2 * ROWB + seg * 1024;
+          if (seg < 4 || lane < 16) __builtin_amdgcn_global_load_lds(src, (lds_ptr_c64)dst, 16, 0, 0);
+        }
+      }
+      ix += 32;
+      if (ix == a.W) { ix = 0; if (++iy == a.H) { iy = 0; ++ib; } }
+    };
+    issue(0);
+    if (ns > 1) issue(1);
+    for (int k = 0; k <= ns + 1; ++k) {
+      if (k + 1 < ns) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");    // patch k landed, patch k + 1 may be in flight
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      handover();
+      if (k + 2 < ns && !(a.dbg & 1)) issue(k + 2);      // its stage held patch k - 2: last read in iteration k - 1
+    }
+  } else {
+    // ---- epilogue of step k - 2: residual, ReLU, 16-byte row pieces of the fp32 and / or split output ----
+    for (int k = 0; k <= ns + 1; ++k) {
+      handover();
+      if (k < 2 || (a.dbg & 2)) continue;
+      const int j = k - 2;
+      const float* Tw = reinterpret_cast<const float*>(lds + OFF_FIN + ((j & 1) * 2 + cb) * FIN);
+      const long long m0 = (long long)(s0 + j) << 5;       // steps are 32 consecutive pixels of the NHWC raster (W % 32 == 0)
+      // all four row pieces requested before the first is used: one LDS and one memory round trip per step, not four
+      float4 v[4], p[4];
+      long long o[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int rl = i * 8 + (lane >> 3), c4 = lane & 7;
-        float4 v = *reinterpret_cast<const float4*>(Tw + rl * TP + c4 * 4);
-        const long long o = (m0 + rl) * 64 + cb * 32 + c4 * 4;
-        if (a.res) {
-          const float4 p = ld4(a.res + o);
-          v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
-        }
-        if (a.relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-        if (a.Y) st4(a.Y + o, v);
-        if (a.Ys) st4_split(a.Ys, a.ys_plane, o, v);
+        v[i] = *reinterpret_cast<const float4*>(Tw + rl * TP + c4 * 4);
+        o[i] = (m0 + rl) * 64 + cb * 32 + c4 * 4;
+        if (a.res) p[i] = ld4(a.res + o[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (a.res) { v[i].x += p[i].x; v[i].y += p[i].y; v[i].z += p[i].z; v[i].w += p[i].w; }
+        if (a.relu) v[i] = make_float4(fmaxf(v[i].x, 0.f), fmaxf(v[i].y, 0.f), fmaxf(v[i].z, 0.f), fmaxf(v[i].w, 0.f));
+        if (a.Y) st4(a.Y + o[i], v[i]);
+        if (a.Ys) st4_split(a.Ys, a.ys_plane, o[i], v[i]);
       }
     }
   }
@@ -215,13 +251,14 @@ int conv64_rows(const ConvSSArgs& c, hipStream_t stream) {
   d.X = (const _Float16*)c.X; d.x_plane = c.x_plane; d.Wh = (const _Float16*)c.Wh; d.Wl = (const _Float16*)c.Wl; d.ldw = c.ldw;
   d.bias = c.bias; d.res = c.res; d.Y = c.Y; d.Ys = (_Float16*)c.Ys; d.ys_plane = c.ys_plane; d.zeros = (const _Float16*)c.zeros;
   d.B = c.B; d.H = c.H; d.W = c.Wd; d.relu = c.relu;
+  d.dbg = g_conv64_dbg;
   d.steps_total = (int)(M / 32);
   int wgs = d.steps_total < 256 ? d.steps_total : 256;
   d.spg = (d.steps_total + wgs - 1) / wgs;
   wgs = (d.steps_total + d.spg - 1) / d.spg;
   const double mnk = (double)M * 64 * 576;
   ProfScope prof("conv64_rows", stream, 2.0 * mnk, 4.0 * ((double)M * 64 * (1 + (c.Y ? 1 : 0) + (c.Ys ? 1 : 0) + (c.res ? 1 : 0)) + 64.0 * 576));
-  hipLaunchKernelGGL(conv64_rows_kernel, dim3(wgs), dim3(256), 0, stream, d);
+  hipLaunchKernelGGL(conv64_rows_kernel, dim3(wgs), dim3(512), 0, stream, d);
   return check_launch("conv64_rows");
 }
 

@@ -251,10 +251,11 @@ int conv64_rows(const ConvSSArgs& c, hipStream_t stream) {
   d.X = (const _Float16*)c.X; d.x_plane = c.x_plane; d.Wh = (const _Float16*)c.Wh; d.Wl = (const _Float16*)c.Wl; d.ldw = c.ldw;
   d.bias = c.bias; d.res = c.res; d.Y = c.Y; d.Ys = (_Float16*)c.Ys; d.ys_plane = c.ys_plane; d.zeros = (const _Float16*)c.zeros;
   d.B = c.B; d.H = c.H; d.W = c.Wd; d.relu = c.relu;
-  d.dbg = g_conv64_dbg;
+  d.dbg = g_conv64_dbg & 255;
   d.steps_total = (int)(M / 32);
   int wgs = d.steps_total < 256 ? d.steps_total : 256;
   d.spg = (d.steps_total + wgs - 1) / wgs;
+  if (g_conv64_dbg >> 8) d.spg = g_conv64_dbg >> 8;      // experiments: steps per workgroup
   wgs = (d.steps_total + d.spg - 1) / d.spg;
   const double mnk = (double)M * 64 * 576;
   ProfScope prof("conv64_rows", stream, 2.0 * mnk, 4.0 * ((double)M * 64 * (1 + (c.Y ? 1 : 0) + (c.Ys ? 1 : 0) + (c.res ? 1 : 0)) + 64.0 * 576));

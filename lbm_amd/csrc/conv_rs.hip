@@ -208,30 +208,72 @@ __global__ __launch_bounds__(512) void conv64_rows_kernel(Conv64Dev a) {
       if (k + 2 < ns && !(a.dbg & 1)) issue(k + 2);      // its stage held patch k - 2: last read in iteration k - 1
     }
   } else {
-    // ---- epilogue of step k - 2: residual, ReLU, 16-byte row pieces of the fp32 and / or split output ----
-    for (int k = 0; k <= ns + 1; ++k) {
-      handover();
-      if (k < 2 || (a.dbg & 2)) continue;
-      const int j = k - 2;
+    // ---- epilogue of step k - 2: residual, ReLU, 16-byte row pieces of the fp32 and / or split output.  The residual rows of a
+    // step are requested two iterations before they are used (three register sets, loop unrolled by three so that no set is ever
+    // moved): a memory round trip per step on this wave's path made the residual form twice as slow as the plain one ----
+    const int lrow = lane >> 3, c4 = lane & 7;
+    const long long lo = (long long)lrow * 64 + cb * 32 + c4 * 4;      // this lane's element inside a step's 32 x 64 block (+ 512 i)
+    f32x4 pr[3][4];
+    const int n_st = (a.Y ? 4 : 0) + (a.Ys ? 8 : 0);              // vector-memory operations of one step's stores
+    // The residual loads are issued from inline asm so that the compiler does not wait for them (it would wait for the NEWEST
+    // set on every back edge); the wait below counts, in issue order, what was issued after the set that is about to be used.
+    auto fetch = [&](auto ic, const int j) __attribute__((always_inline)) {
+      constexpr int I = decltype(ic)::value;
+      if (a.res == nullptr || j >= ns) return;
+      const float* rp = a.res + ((long long)(s0 + j) << 11) + lo;     // steps are 32 consecutive pixels of the NHWC raster (W % 32 == 0)
+      f32x4 &p0 = pr[I][0], &p1 = pr[I][1], &p2 = pr[I][2], &p3 = pr[I][3];
+      asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:2048\n\t"
+                   "global_load_dwordx4 %2, %5, off\n\tglobal_load_dwordx4 %3, %5, off offset:2048"
+                   : "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3) : "v"(rp), "v"(rp + 1024) : "memory");
+    };
+    auto wait_newer = [&](const int n) __attribute__((always_inline)) {       // n: a multiple of 4 in [0, 32]
+      switch (n >> 2) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(28)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
+      }
+    };
+    auto finish = [&](auto ic, const int j) __attribute__((always_inline)) {
+      constexpr int I = decltype(ic)::value;
       const float* Tw = reinterpret_cast<const float*>(lds + OFF_FIN + ((j & 1) * 2 + cb) * FIN);
-      const long long m0 = (long long)(s0 + j) << 5;       // steps are 32 consecutive pixels of the NHWC raster (W % 32 == 0)
-      // all four row pieces requested before the first is used: one LDS and one memory round trip per step, not four
-      float4 v[4], p[4];
-      long long o[4];
+      const long long o0 = ((long long)(s0 + j) << 11) + lo;
+      float4 v[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int rl = i * 8 + (lane >> 3), c4 = lane & 7;
-        v[i] = *reinterpret_cast<const float4*>(Tw + rl * TP + c4 * 4);
-        o[i] = (m0 + rl) * 64 + cb * 32 + c4 * 4;
-        if (a.res) p[i] = ld4(a.res + o[i]);
+      for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const float4*>(Tw + (i * 8 + lrow) * TP + c4 * 4);
+      if (a.res) {
+        // issued after this step's residual set (k = j + 2): stores of step j - 2 and j - 1, residual sets of steps j + 1 and j + 2
+        const int k = j + 2;
+        wait_newer((k - 1 < ns ? 4 : 0) + (k < ns ? 4 : 0) + n_st * ((k >= 4 ? 1 : 0) + (k >= 3 ? 1 : 0)));
+        f32x4 &p0 = pr[I][0], &p1 = pr[I][1], &p2 = pr[I][2], &p3 = pr[I][3];
+        asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        if (a.res) { v[i].x += p[i].x; v[i].y += p[i].y; v[i].z += p[i].z; v[i].w += p[i].w; }
+        if (a.res) { v[i].x += pr[I][i][0]; v[i].y += pr[I][i][1]; v[i].z += pr[I][i][2]; v[i].w += pr[I][i][3]; }
         if (a.relu) v[i] = make_float4(fmaxf(v[i].x, 0.f), fmaxf(v[i].y, 0.f), fmaxf(v[i].z, 0.f), fmaxf(v[i].w, 0.f));
-        if (a.Y) st4(a.Y + o[i], v[i]);
-        if (a.Ys) st4_split(a.Ys, a.ys_plane, o[i], v[i]);
+        if (a.Y) st4(a.Y + o0 + i * 512, v[i]);
+        if (a.Ys) st4_split(a.Ys, a.ys_plane, o0 + i * 512, v[i]);
       }
+    };
+    // iteration k: request the residual of step k (set k % 3), finish step k - 2 (set (k + 1) % 3)
+    auto iter = [&](auto ic, const int k) __attribute__((always_inline)) {
+      constexpr int I = decltype(ic)::value;
+      handover();
+      fetch(ic, k);
+      if (k >= 2 && !(a.dbg & 2)) finish(std::integral_constant<int, (I + 1) % 3>{}, k - 2);
+    };
+    for (int k = 0; k <= ns + 1; k += 3) {
+      iter(std::integral_constant<int, 0>{}, k);
+      if (k + 1 > ns + 1) break;
+      iter(std::integral_constant<int, 1>{}, k + 1);
+      if (k + 2 > ns + 1) break;
+      iter(std::integral_constant<int, 2>{}, k + 2);
     }
   }
 #endif

@@ -322,7 +322,7 @@ __global__ __launch_bounds__(512) void gemm_rs_kernel(GemmRSDev a) {
       if (more) wait_vm<4>();
       else wait_vm<0>();
     }
-    __builtin_amdgcn_s_barrier();          // every wave's pieces of step s are in; every wave is done reading step s - 1
+    if (!(a.dbg & 2048)) __builtin_amdgcn_s_barrier();          // every wave's pieces of step s are in; every wave is done reading step s - 1
     const unsigned char* Ab = lds + (s % NS) * STAGE;
     const bool mm = active && !(a.dbg & 8);
     if (mm) ldg(Ab, 0, 0);                 // in flight under the epilogue / DMA issue below

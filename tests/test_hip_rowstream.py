@@ -141,11 +141,13 @@ def test_many_rows_feed_forward_leaves_the_same_slabs_as_the_few_rows_kernel(hip
     assert float((b.sum(0).double() - want).abs().max()) < 2e-5 * max(1.0, float(want.abs().max()))
 
 
-@pytest.mark.parametrize("B,H,W", [(1, 5, 32), (2, 24, 64), (3, 7, 96), (4, 96, 128)])
-@pytest.mark.parametrize("relu,use_res,f32,split", [(True, False, False, True), (True, True, True, True), (False, False, True, False)])
+@pytest.mark.parametrize("B,H,W", [(1, 5, 32), (2, 24, 64), (3, 7, 96), (4, 96, 128), (16, 96, 128)])
+@pytest.mark.parametrize("relu,use_res,f32,split", [(True, False, False, True), (True, True, True, True), (False, False, True, False),
+                                                    (True, True, True, False), (False, True, False, True)])
 def test_patch_streaming_convolution_is_bit_identical_to_the_tiled_one(hip, B, H, W, relu, use_res, f32, split):
     """conv64_rows_kernel (3 x 3, stride 1, 64 -> 64; debug key 4 = 16) against the tiled implicit GEMM (key 4 = 15): same accumulation
-    chain, so every output must agree bit for bit -- borders (zero padding), one-row images and every output combination included."""
+    chain, so every output must agree bit for bit -- borders (zero padding), one-row images, every output combination (the residual
+    rows are fetched two steps ahead behind a wait that counts the stores of each combination) and 1 to 24 steps per workgroup."""
     lib = hip.load()
     g = torch.Generator(device="cpu").manual_seed(B * 100 + H)
     x = torch.randn(B, H, W, 64, generator=g).cuda()

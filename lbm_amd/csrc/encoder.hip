@@ -19,6 +19,16 @@ __device__ __forceinline__ void resize_coeff(int dst, float scale, int in, int& 
 // T = uint8_t: the decoder's own bytes (demo_utils.py:127-131 converts them to float on the host, 4x the bytes over PCIe and
 //   out of HBM): LAYOUT 0 planar (B,3,H,W) RGB; 1 interleaved (B,H,W,3) RGB; 2 interleaved (B,H,W,3) BGR (cv2's order).
 //   uint8 -> float is exact, so the result is bit-identical to the fp32 path on the same values.
+// Bilinear blend + normalisation of one value with every rounding spelled out: the two preprocess kernels below must give the same
+// bits, and left to itself the compiler contracts the blend into fused multiply-adds differently in each.
+__device__ __forceinline__ float resize_norm(float v00, float v01, float v10, float v11, float lx0, float lx1, float ly0, float ly1,
+                                             float mean, float sd) {
+  const float top = __fmaf_rn(lx0, v00, __fmul_rn(lx1, v01));
+  const float bot = __fmaf_rn(lx0, v10, __fmul_rn(lx1, v11));
+  const float v = __fmaf_rn(ly0, top, __fmul_rn(ly1, bot));
+  return __fdiv_rn(__fsub_rn(v, mean), sd);
+}
+
 template <typename T, int LAYOUT>
 __global__ __launch_bounds__(256) void preprocess_kernel(const T* __restrict__ in, float* __restrict__ out, int B, int H,
                                                          int W, int oh, int ow, long long in_bstride, int out_nhwc) {
@@ -40,14 +50,44 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const T* __restrict__ i
     };
     const float v00 = px(y0, x0) / 255.0f, v01 = px(y0, x1) / 255.0f;
     const float v10 = px(y1, x0) / 255.0f, v11 = px(y1, x1) / 255.0f;
-    const float v = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
     const float mean = c == 0 ? 0.485f : (c == 1 ? 0.456f : 0.406f);
     const float sd = c == 0 ? 0.229f : (c == 1 ? 0.224f : 0.225f);
     // out_nhwc: 0 = [B,3,oh,ow]; 3 or 4 = pixel-major with that many channels (channel 3 zero-filled)
     const long long o = out_nhwc ? (((long long)b * oh + y) * ow + x) * out_nhwc + c : i;
-    out[o] = (v - mean) / sd;
+    out[o] = resize_norm(v00, v01, v10, v11, lx0, lx1, ly0, ly1, mean, sd);
     if (out_nhwc == 4 && c == 0) out[o + 3] = 0.f;
   }
+}
+
+// The 4-channel pixel-major form the encoder takes: one thread per output pixel (the per-element form above writes the three
+// channels of a pixel from three different waves, 4 bytes at a 16-byte stride: 1.9 TB/s at 64 frames).  Same arithmetic per value.
+template <typename T, int LAYOUT>
+__global__ __launch_bounds__(256) void preprocess_px_kernel(const T* __restrict__ in, float* __restrict__ out, int B, int H, int W, int oh,
+                                                            int ow, long long in_bstride) {
+  const float sy = (float)H / (float)oh, sx = (float)W / (float)ow;
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int b = blockIdx.z;
+  if (x >= ow || y >= oh) return;
+  int y0, y1, x0, x1;
+  float ly0, ly1, lx0, lx1;
+  resize_coeff(y, sy, H, y0, y1, ly0, ly1);
+  resize_coeff(x, sx, W, x0, x1, lx0, lx1);
+  const T* p = in + (long long)b * in_bstride;
+  float r[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    auto px = [&](int yy, int xx) {
+      if constexpr (LAYOUT == 0) return (float)p[(long long)c * H * W + (long long)yy * W + xx];
+      else return (float)p[((long long)yy * W + xx) * 3 + (LAYOUT == 2 ? 2 - c : c)];
+    };
+    const float v00 = px(y0, x0) / 255.0f, v01 = px(y0, x1) / 255.0f;
+    const float v10 = px(y1, x0) / 255.0f, v11 = px(y1, x1) / 255.0f;
+    const float mean = c == 0 ? 0.485f : (c == 1 ? 0.456f : 0.406f);
+    const float sd = c == 0 ? 0.229f : (c == 1 ? 0.224f : 0.225f);
+    r[c] = resize_norm(v00, v01, v10, v11, lx0, lx1, ly0, ly1, mean, sd);
+  }
+  st4(out + (((long long)b * oh + y) * ow + x) * 4, make_float4(r[0], r[1], r[2], 0.f));
 }
 
 static int preprocess_check(const void* frames, float* out, int B, int H, int W, int oh, int ow, int out_nhwc, long long& blocks) {
@@ -63,6 +103,10 @@ int preprocess(const float* frames, long long frame_bstride, float* out, int B, 
   long long blocks;
   if (preprocess_check(frames, out, B, H, W, oh, ow, out_nhwc, blocks)) return -1;
   ProfScope prof("preprocess", stream, 0.0, 4.0 * B * 3 * ((double)H * W + (double)oh * ow));
+  if (out_nhwc == 4 && B <= 65535) {
+    hipLaunchKernelGGL((preprocess_px_kernel<float, 0>), dim3((ow + 63) / 64, (oh + 3) / 4, B), dim3(256), 0, stream, frames, out, B, H, W, oh, ow, frame_bstride);
+    return check_launch("preprocess");
+  }
   hipLaunchKernelGGL((preprocess_kernel<float, 0>), dim3((unsigned)blocks), dim3(256), 0, stream, frames, out, B, H, W, oh, ow, frame_bstride, out_nhwc);
   return check_launch("preprocess");
 }
@@ -74,6 +118,13 @@ int preprocess_u8(const uint8_t* frames, long long frame_bstride, int in_layout,
   LBM_REQUIRE(in_layout >= 0 && in_layout <= 2, "preprocess_u8: in_layout must be 0 (planar RGB), 1 (interleaved RGB) or 2 (interleaved BGR)");
   ProfScope prof("preprocess_u8", stream, 0.0, (double)B * 3 * ((double)H * W + 4.0 * oh * ow));
   const dim3 grid((unsigned)blocks), blk(256);
+  if (out_nhwc == 4 && B <= 65535) {
+    const dim3 gp((ow + 63) / 64, (oh + 3) / 4, B);
+    if (in_layout == 0) hipLaunchKernelGGL((preprocess_px_kernel<uint8_t, 0>), gp, blk, 0, stream, frames, out, B, H, W, oh, ow, frame_bstride);
+    else if (in_layout == 1) hipLaunchKernelGGL((preprocess_px_kernel<uint8_t, 1>), gp, blk, 0, stream, frames, out, B, H, W, oh, ow, frame_bstride);
+    else hipLaunchKernelGGL((preprocess_px_kernel<uint8_t, 2>), gp, blk, 0, stream, frames, out, B, H, W, oh, ow, frame_bstride);
+    return check_launch("preprocess_u8");
+  }
   if (in_layout == 0) hipLaunchKernelGGL((preprocess_kernel<uint8_t, 0>), grid, blk, 0, stream, frames, out, B, H, W, oh, ow, frame_bstride, out_nhwc);
   else if (in_layout == 1) hipLaunchKernelGGL((preprocess_kernel<uint8_t, 1>), grid, blk, 0, stream, frames, out, B, H, W, oh, ow, frame_bstride, out_nhwc);
   else hipLaunchKernelGGL((preprocess_kernel<uint8_t, 2>), grid, blk, 0, stream, frames, out, B, H, W, oh, ow, frame_bstride, out_nhwc);

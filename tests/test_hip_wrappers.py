@@ -115,7 +115,10 @@ def test_uint8_frames_track_bit_identically_to_float_frames(gold):
     hwc = v8[0, :2].permute(0, 2, 3, 1).contiguous()
     assert torch.equal(hip.preprocess(hwc, SIZE[0], SIZE[1], layout=4, u8_layout="hwc_rgb"), want)
     assert torch.equal(hip.preprocess(hwc.flip(-1).contiguous(), SIZE[0], SIZE[1], layout=4, u8_layout="hwc_bgr"), want)
-    assert torch.equal(hip.preprocess(v8[0, :2], SIZE[0], SIZE[1], layout=0), hip.preprocess(video[0, :2], SIZE[0], SIZE[1], layout=0))
+    planar = hip.preprocess(video[0, :2], SIZE[0], SIZE[1], layout=0)
+    assert torch.equal(hip.preprocess(v8[0, :2], SIZE[0], SIZE[1], layout=0), planar)
+    # the pixel-major kernel (one thread per pixel) against the element-wise one: same bits, fourth channel zero
+    assert torch.equal(want[..., :3], planar.permute(0, 2, 3, 1)) and not want[..., 3].any()
     a, b = _model("LBM_online"), _model("LBM_online")
     with torch.no_grad():
         a.init(inp["pts0"].cuda(), video[:, 0])

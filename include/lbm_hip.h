@@ -146,6 +146,17 @@ int lbm_hip_preprocess(const float* frames, int64_t frame_bstride, float* out, i
  * the same pixel values.                                                                                                   */
 int lbm_hip_preprocess_u8(const uint8_t* frames, int64_t frame_bstride, int32_t in_layout, float* out, int32_t B, int32_t H, int32_t W,
                           int32_t oh, int32_t ow, int32_t out_nhwc, lbm_stream_t stream);
+/* The same pre-processing into f16 hi / lo planes [2][B, oh, ow, 4] (value = hi + lo / 2048, channel 3 zero): what lbm_hip_stem_pool
+ * reads.  is_u8 = 0: planar fp32 frames as lbm_hip_preprocess (in_layout 0); 1: bytes as lbm_hip_preprocess_u8.  out_plane in elements. */
+int lbm_hip_preprocess_split(const void* frames, int32_t is_u8, int64_t frame_bstride, int32_t in_layout, void* out_hi, int64_t out_plane,
+                             int32_t B, int32_t H, int32_t W, int32_t oh, int32_t ow, lbm_stream_t stream);
+/* The ResNet stem in one launch (backbone.py:48-50 = torchvision conv1 / bn1 / relu / maxpool with the BatchNorm folded into W and
+ * bias): 7 x 7 stride-2 pad-3 convolution 4 -> 64 channels over split planes X [2][B, H, W, 4], ReLU, 3 x 3 stride-2 pad-1
+ * max-pooling; Y fp32 and / or Ys split planes [B, H / 4, W / 4, 64].  W_hi / W_lo: [64, ldw] with columns (ky, kx, c), c < 4, as
+ * lbm_hip_conv2d_nhwc takes them.  H and W must be multiples of 4.  Replaces lbm_hip_conv2d_nhwc + lbm_hip_maxpool3x3s2_nhwc_s
+ * for the stem: same values up to the summation order inside the matrix cores (about 1e-7 relative).                          */
+int lbm_hip_stem_pool(const void* X, int64_t x_plane, const void* W_hi, const void* W_lo, int32_t ldw, const float* bias, float* Y, void* Ys,
+                      int64_t ys_plane, int32_t B, int32_t H, int32_t W, lbm_stream_t stream);
 int lbm_hip_upcat(const float* p1, const float* p2, const float* p3, float* out, int32_t B, int32_t h, int32_t w,
                   lbm_stream_t stream);
 int lbm_hip_sample_queries(const float* tokens, int64_t tok_bstride, int32_t ld, const float* pts, float* out,

@@ -782,6 +782,16 @@ int lbm_hip_preprocess_u8(const uint8_t* frames, int64_t frame_bstride, int32_t 
   return preprocess_u8(frames, frame_bstride, in_layout, out, B, H, W, oh, ow, out_nhwc, (hipStream_t)stream);
 }
 
+int lbm_hip_preprocess_split(const void* frames, int32_t is_u8, int64_t frame_bstride, int32_t in_layout, void* out_hi, int64_t out_plane,
+                             int32_t B, int32_t H, int32_t W, int32_t oh, int32_t ow, lbm_stream_t stream) {
+  return preprocess_split(frames, is_u8, frame_bstride, in_layout, out_hi, out_plane, B, H, W, oh, ow, (hipStream_t)stream);
+}
+
+int lbm_hip_stem_pool(const void* X, int64_t x_plane, const void* W_hi, const void* W_lo, int32_t ldw, const float* bias, float* Y, void* Ys,
+                      int64_t ys_plane, int32_t B, int32_t H, int32_t W, lbm_stream_t stream) {
+  return stem_pool(X, x_plane, W_hi, W_lo, ldw, bias, Y, Ys, ys_plane, B, H, W, (hipStream_t)stream);
+}
+
 int lbm_hip_upcat(const float* p1, const float* p2, const float* p3, float* out, int32_t B, int32_t h, int32_t w,
                   lbm_stream_t stream) {
   return upcat(p1, p2, p3, out, B, h, w, (hipStream_t)stream);

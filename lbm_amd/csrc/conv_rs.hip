@@ -46,7 +46,7 @@ struct Conv64Dev {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_c64;
 
-static __device__ __align__(256) unsigned char g_zero_row[34 * 128];      // what rows above / below the image and pixels -1 / W read (never written)
+[[maybe_unused]] static __device__ __align__(256) unsigned char g_zero_row[34 * 128];      // what rows above / below the image and pixels -1 / W read (never written)
 
 __global__ __launch_bounds__(512) void conv64_rows_kernel(Conv64Dev a) {
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const T* __restrict__ i
 // channels of a pixel from three different waves, 4 bytes at a 16-byte stride: 1.9 TB/s at 64 frames).  Same arithmetic per value.
 template <typename T, int LAYOUT>
 __global__ __launch_bounds__(256) void preprocess_px_kernel(const T* __restrict__ in, float* __restrict__ out, int B, int H, int W, int oh,
-                                                            int ow, long long in_bstride) {
+                                                            int ow, long long in_bstride, void* outs = nullptr, long long outs_plane = 0) {
   const float sy = (float)H / (float)oh, sx = (float)W / (float)ow;
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -87,7 +87,25 @@ __global__ __launch_bounds__(256) void preprocess_px_kernel(const T* __restrict_
     const float sd = c == 0 ? 0.229f : (c == 1 ? 0.224f : 0.225f);
     r[c] = resize_norm(v00, v01, v10, v11, lx0, lx1, ly0, ly1, mean, sd);
   }
-  st4(out + (((long long)b * oh + y) * ow + x) * 4, make_float4(r[0], r[1], r[2], 0.f));
+  const long long o = (((long long)b * oh + y) * ow + x) * 4;
+  if (out) st4(out + o, make_float4(r[0], r[1], r[2], 0.f));
+  if (outs) st4_split(outs, outs_plane, o, make_float4(r[0], r[1], r[2], 0.f));      // what stem_pool reads (stem_rs.hip)
+}
+
+// frames -> split planes [2][B, oh, ow, 4] directly (is_u8: in_layout as preprocess_u8, else planar fp32)
+int preprocess_split(const void* frames, int is_u8, long long frame_bstride, int in_layout, void* outs, long long outs_plane, int B, int H,
+                     int W, int oh, int ow, hipStream_t stream) {
+  LBM_REQUIRE(frames && outs && B > 0 && B <= 65535 && H > 0 && W > 0 && oh > 0 && ow > 0, "preprocess_split: bad arguments");
+  LBM_REQUIRE(((uintptr_t)outs & 7) == 0 && outs_plane % 4 == 0, "preprocess_split: output planes must be 8-byte aligned");
+  LBM_REQUIRE(!is_u8 ? in_layout == 0 : (in_layout >= 0 && in_layout <= 2), "preprocess_split: in_layout must be 0 (planar RGB), 1 (interleaved RGB) or 2 (interleaved BGR)");
+  ProfScope prof("preprocess", stream, 0.0, (is_u8 ? 1.0 : 4.0) * B * 3 * (double)H * W + 16.0 * B * (double)oh * ow);
+  const dim3 gp((ow + 63) / 64, (oh + 3) / 4, B), blk(256);
+  float* none = nullptr;
+  if (!is_u8) hipLaunchKernelGGL((preprocess_px_kernel<float, 0>), gp, blk, 0, stream, (const float*)frames, none, B, H, W, oh, ow, frame_bstride, outs, outs_plane);
+  else if (in_layout == 0) hipLaunchKernelGGL((preprocess_px_kernel<uint8_t, 0>), gp, blk, 0, stream, (const uint8_t*)frames, none, B, H, W, oh, ow, frame_bstride, outs, outs_plane);
+  else if (in_layout == 1) hipLaunchKernelGGL((preprocess_px_kernel<uint8_t, 1>), gp, blk, 0, stream, (const uint8_t*)frames, none, B, H, W, oh, ow, frame_bstride, outs, outs_plane);
+  else hipLaunchKernelGGL((preprocess_px_kernel<uint8_t, 2>), gp, blk, 0, stream, (const uint8_t*)frames, none, B, H, W, oh, ow, frame_bstride, outs, outs_plane);
+  return check_launch("preprocess_split");
 }
 
 static int preprocess_check(const void* frames, float* out, int B, int H, int W, int oh, int ow, int out_nhwc, long long& blocks) {
@@ -104,7 +122,7 @@ int preprocess(const float* frames, long long frame_bstride, float* out, int B, 
   if (preprocess_check(frames, out, B, H, W, oh, ow, out_nhwc, blocks)) return -1;
   ProfScope prof("preprocess", stream, 0.0, 4.0 * B * 3 * ((double)H * W + (double)oh * ow));
   if (out_nhwc == 4 && B <= 65535) {
-    hipLaunchKernelGGL((preprocess_px_kernel<float, 0>), dim3((ow + 63) / 64, (oh + 3) / 4, B), dim3(256), 0, stream, frames, out, B, H, W, oh, ow, frame_bstride);
+    hipLaunchKernelGGL((preprocess_px_kernel<float, 0>), dim3((ow + 63) / 64, (oh + 3) / 4, B), dim3(256), 0, stream, frames, out, B, H, W, oh, ow, frame_bstride, (void*)nullptr, 0LL);
     return check_launch("preprocess");
   }
   hipLaunchKernelGGL((preprocess_kernel<float, 0>), dim3((unsigned)blocks), dim3(256), 0, stream, frames, out, B, H, W, oh, ow, frame_bstride, out_nhwc);
@@ -120,9 +138,9 @@ int preprocess_u8(const uint8_t* frames, long long frame_bstride, int in_layout,
   const dim3 grid((unsigned)blocks), blk(256);
   if (out_nhwc == 4 && B <= 65535) {
     const dim3 gp((ow + 63) / 64, (oh + 3) / 4, B);
-    if (in_layout == 0) hipLaunchKernelGGL((preprocess_px_kernel<uint8_t, 0>), gp, blk, 0, stream, frames, out, B, H, W, oh, ow, frame_bstride);
-    else if (in_layout == 1) hipLaunchKernelGGL((preprocess_px_kernel<uint8_t, 1>), gp, blk, 0, stream, frames, out, B, H, W, oh, ow, frame_bstride);
-    else hipLaunchKernelGGL((preprocess_px_kernel<uint8_t, 2>), gp, blk, 0, stream, frames, out, B, H, W, oh, ow, frame_bstride);
+    if (in_layout == 0) hipLaunchKernelGGL((preprocess_px_kernel<uint8_t, 0>), gp, blk, 0, stream, frames, out, B, H, W, oh, ow, frame_bstride, (void*)nullptr, 0LL);
+    else if (in_layout == 1) hipLaunchKernelGGL((preprocess_px_kernel<uint8_t, 1>), gp, blk, 0, stream, frames, out, B, H, W, oh, ow, frame_bstride, (void*)nullptr, 0LL);
+    else hipLaunchKernelGGL((preprocess_px_kernel<uint8_t, 2>), gp, blk, 0, stream, frames, out, B, H, W, oh, ow, frame_bstride, (void*)nullptr, 0LL);
     return check_launch("preprocess_u8");
   }
   if (in_layout == 0) hipLaunchKernelGGL((preprocess_kernel<uint8_t, 0>), grid, blk, 0, stream, frames, out, B, H, W, oh, ow, frame_bstride, out_nhwc);

@@ -131,10 +131,19 @@ class EncoderWeights:
         # positional embedding, token-major (P0, 256)
         self.pos = f32(_f64(bb.frame_pos_embedding)[0].permute(1, 2, 0).reshape(self.P0, -1))
 
+    @property
+    def _fused_stem(self) -> bool:
+        """conv1 + bn1 + relu + maxpool as ONE launch over split input planes (stem_rs.hip); LBM_AMD_FUSED_STEM=0: the two kernels."""
+        import os
+        return (self.precision == "split" and self.size[0] % 4 == 0 and self.size[1] % 4 == 0 and
+                os.environ.get("LBM_AMD_FUSED_STEM", "1") != "0")
+
     def encode(self, frames: torch.Tensor, out: Optional[torch.Tensor] = None,
                split_out: Optional["hip.SplitTensor"] = None) -> torch.Tensor:
         """split_out: caller-owned split twin to fill instead of the encoder's own (double-buffered pipelines)."""
         self._split_target = split_out
+        if self._fused_stem:
+            return self._body_split(hip.preprocess_split(frames, self.size[0], self.size[1]), True, out)
         x = hip.preprocess(frames, self.size[0], self.size[1], layout=4)
         return self._body(x, True, out)
 
@@ -170,8 +179,11 @@ class EncoderWeights:
         B = x.shape[0]
         if self._scratch is None:
             self._scratch = torch.empty(32 << 20, device=self.dev, dtype=torch.uint8)    # K-split slabs of small convolutions
-        y = self.stem.loader_split(x, True)
-        y, ys = hip.maxpool3x3s2_nhwc_s(y)
+        if self._fused_stem:
+            y, ys = hip.stem_pool(x if isinstance(x, hip.SplitTensor) else hip.split_tensor(x), self.stem.ws, self.stem.b)
+        else:
+            y = self.stem.loader_split(x, True)
+            y, ys = hip.maxpool3x3s2_nhwc_s(y)
         feats = []
         for i, (c1, c2, down) in enumerate(self.blocks):
             idn = y if down is None else down.split(ys, False, want_split=False, scratch=self._scratch, planes=self.planes)[0]

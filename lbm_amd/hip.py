@@ -29,7 +29,7 @@ EXPORTS = (
     "lbm_hip_conv2d_nhwc_ss", "lbm_hip_maxpool3x3s2_nhwc_s", "lbm_hip_upcat_s", "lbm_hip_pyramid_s",
     "lbm_hip_update_points", "lbm_hip_encoder_tail", "lbm_hip_pack_fragment_major", "lbm_hip_ffn_slabs",
     "lbm_hip_debug_ptr", "lbm_hip_update_points_static", "lbm_hip_preprocess_u8", "lbm_hip_corr_topk",
-    "lbm_hip_corr_topk_workspace_bytes",
+    "lbm_hip_corr_topk_workspace_bytes", "lbm_hip_preprocess_split", "lbm_hip_stem_pool",
 )
 
 
@@ -161,6 +161,9 @@ def load() -> C.CDLL:
     lib.lbm_hip_split_planes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.lbm_hip_profile_end.argtypes = [C.POINTER(ProfileEntry), C.c_int32]
     lib.lbm_hip_debug_ptr.argtypes = [C.c_int32, C.c_void_p]
+    lib.lbm_hip_preprocess_split.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_int64] + [C.c_int32] * 5 + [C.c_void_p]
+    lib.lbm_hip_stem_pool.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                      C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     lib.lbm_hip_corr_topk_workspace_bytes.restype = C.c_int64
     lib.lbm_hip_corr_topk_workspace_bytes.argtypes = [C.c_int32] * 4
     lib.lbm_hip_corr_topk.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
@@ -267,6 +270,15 @@ class SplitTensor:
         t.planes = self.planes.view(2, *shape)
         t.shape = tuple(t.planes.shape[1:])
         return t
+
+
+def split_tensor(x: torch.Tensor) -> SplitTensor:
+    """fp32 tensor -> its split twin (lbm_hip_split_planes)."""
+    _require_gpu()
+    x = x.float().contiguous()
+    t = SplitTensor(tuple(x.shape), x.device)
+    _check(load().lbm_hip_split_planes(x.data_ptr(), t.planes[0].data_ptr(), t.planes[1].data_ptr(), x.numel(), _stream()), "lbm_hip_split_planes")
+    return t
 
 
 _zeros: Dict[str, torch.Tensor] = {}
@@ -622,6 +634,35 @@ def preprocess(frames: torch.Tensor, oh: int, ow: int, layout: int = 0, u8_layou
         _check(load().lbm_hip_preprocess(frames.data_ptr(), 3 * H * W, out.data_ptr(), B, H, W, oh, ow, layout, _stream()),
                "lbm_hip_preprocess")
     return out
+
+
+def preprocess_split(frames: torch.Tensor, oh: int, ow: int, u8_layout: str = "chw") -> "SplitTensor":
+    """preprocess(..., layout=4) written as f16 hi / lo planes (B, oh, ow, 4): the input of stem_pool."""
+    _require_gpu()
+    is_u8 = frames.dtype == torch.uint8
+    code = U8_LAYOUTS[u8_layout] if is_u8 else 0
+    frames = frames.contiguous() if is_u8 else frames.float().contiguous()
+    if code == 0:
+        B, Cc, H, W = frames.shape
+    else:
+        B, H, W, Cc = frames.shape
+    assert Cc == 3
+    out = SplitTensor((B, oh, ow, 4), frames.device)
+    _check(load().lbm_hip_preprocess_split(frames.data_ptr(), int(is_u8), 3 * H * W, code, out.hi, out.plane, B, H, W, oh, ow, _stream()),
+           "lbm_hip_preprocess_split")
+    return out
+
+
+def stem_pool(xs: "SplitTensor", w: "SplitWeight", bias: torch.Tensor, want_f32: bool = True, want_split: bool = True):
+    """conv 7 x 7 / 2 (4 -> 64 channels, BatchNorm folded) + ReLU + max-pool 3 x 3 / 2 in one launch; xs: split (B, H, W, 4)."""
+    _require_gpu()
+    B, H, W, Cc = xs.shape
+    assert Cc == 4 and w.shape[0] == 64
+    y = torch.empty(B, H // 4, W // 4, 64, device=xs.planes.device, dtype=torch.float32) if want_f32 else None
+    ys = SplitTensor((B, H // 4, W // 4, 64), xs.planes.device) if want_split else None
+    _check(load().lbm_hip_stem_pool(xs.hi, xs.plane, w.hi, w.lo, w.shape[1], _p(bias), _p(y), ys.hi if ys else None, ys.plane if ys else 0,
+                                    B, H, W, _stream()), "lbm_hip_stem_pool")
+    return y, ys
 
 
 def upcat(p1, p2, p3, B, h, w) -> torch.Tensor:

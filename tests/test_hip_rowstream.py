@@ -170,3 +170,43 @@ def test_patch_streaming_convolution_is_bit_identical_to_the_tiled_one(hip, B, H
         assert torch.equal(y0.view(torch.int32), y1.view(torch.int32))
     if split:
         assert torch.equal(s0.planes.view(torch.int16), s1.planes.view(torch.int16))
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 8, 8), (2, 36, 124), (1, 96, 128), (3, 64, 256), (1, 384, 512)])
+def test_fused_stem_matches_convolution_relu_maxpool(hip, B, H, W):
+    """stem_pool (7 x 7 / 2 convolution + ReLU + 3 x 3 / 2 max-pooling in one launch, stem_rs.hip) against the two separate kernels
+    and against float64 torch: image borders, strips that end past the image, one to many pooled rows per workgroup."""
+    g = torch.Generator(device="cpu").manual_seed(B * 1000 + H + W)
+    x = torch.zeros(B, H, W, 4)
+    x[..., :3] = torch.randn(B, H, W, 3, generator=g) * 2.0
+    w4 = torch.randn(64, 4, 7, 7, generator=g) * 0.05
+    w4[:, 3] = 0
+    bias = torch.randn(64, generator=g) * 0.5
+    flat = w4.permute(0, 2, 3, 1).reshape(64, 196)
+    flat = torch.cat([flat, torch.zeros(64, 28)], 1).contiguous()
+    ws = hip.SplitWeight(flat.cuda())
+    xs = hip.split_tensor(x.cuda())
+    y, ys = hip.stem_pool(xs, ws, bias.cuda())
+    want = torch.nn.functional.max_pool2d(torch.relu(torch.nn.functional.conv2d(
+        x.permute(0, 3, 1, 2).double(), w4.double(), bias.double(), stride=2, padding=3)), 3, 2, 1).permute(0, 2, 3, 1)
+    assert y.shape == want.shape
+    tol = 3e-6 * max(1.0, float(want.abs().max()))
+    assert float((y.double().cpu() - want).abs().max()) < tol
+    assert float((ys.float().double().cpu() - want).abs().max()) < tol
+    # the two-kernel path on the same operands: same values up to the summation order inside the matrix cores
+    c = hip.conv2d_nhwc(x.cuda(), ws, bias.cuda(), 7, 7, 2, 3, True, None)
+    y2, ys2 = hip.maxpool3x3s2_nhwc_s(c)
+    assert float((y - y2).abs().max()) < tol
+    only_split = hip.stem_pool(xs, ws, bias.cuda(), want_f32=False)
+    assert only_split[0] is None and torch.equal(only_split[1].planes.view(torch.int16), ys.planes.view(torch.int16))
+
+
+def test_preprocess_split_is_the_split_of_preprocess(hip):
+    g = torch.Generator(device="cpu").manual_seed(5)
+    frames = torch.randint(0, 256, (2, 3, 60, 90), generator=g, dtype=torch.uint8).cuda()
+    want = hip.split_tensor(hip.preprocess(frames.float(), 48, 64, layout=4))
+    for f in (frames, frames.float()):
+        got = hip.preprocess_split(f, 48, 64)
+        assert torch.equal(got.planes.view(torch.int16), want.planes.view(torch.int16))
+    hwc = frames.permute(0, 2, 3, 1).contiguous()
+    assert torch.equal(hip.preprocess_split(hwc.flip(-1).contiguous(), 48, 64, "hwc_bgr").planes.view(torch.int16), want.planes.view(torch.int16))

@@ -346,6 +346,12 @@ typedef struct {
  * != NULL) the split twin of the whole buffer.                                                                  */
 int lbm_hip_encoder_tail(const float* q1, const float* q2, const float* q3, const float* pos, float* tokens, void* tokens_s,
                          int64_t tokens_plane, int32_t B, int32_t h, int32_t w, lbm_stream_t stream);
+/* The same with the finest level's product inside: q1 = f1 . W1^T + b1 is formed per 8 x 8 block of cells on the matrix cores
+ * (f1: split planes [B, h*w, 64] of the layer-1 features, W1_hi / W1_lo: [256, ldw1] split weights of (fusion o proj1), b1 [256] or
+ * NULL) and never reaches memory.  Bit-identical tokens to lbm_hip_linear_ss + lbm_hip_encoder_tail.                          */
+int lbm_hip_encoder_tail_fused(const void* f1, int64_t f1_plane, const void* W1_hi, const void* W1_lo, int32_t ldw1, const float* b1,
+                               const float* q2, const float* q3, const float* pos, float* tokens, void* tokens_s, int64_t tokens_plane,
+                               int32_t B, int32_t h, int32_t w, lbm_stream_t stream);
 
 /* Fragment-major copy of a split weight matrix [N, K] (N % 32 == 0, K % 16 == 0): out[N/32][K/16][2][64][8] f16 -- for every
  * (32-row block, 16-deep k step) the 64 lanes' MFMA operand fragments of the hi plane, then of the lo plane, contiguous, so

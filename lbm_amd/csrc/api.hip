@@ -978,6 +978,12 @@ int lbm_hip_encoder_tail(const float* q1, const float* q2, const float* q3, cons
   return encoder_tail(q1, q2, q3, pos, tokens, B, h, w, (hipStream_t)stream, tokens_s, tokens_plane);
 }
 
+int lbm_hip_encoder_tail_fused(const void* f1, int64_t f1_plane, const void* W1_hi, const void* W1_lo, int32_t ldw1, const float* b1,
+                               const float* q2, const float* q3, const float* pos, float* tokens, void* tokens_s, int64_t tokens_plane,
+                               int32_t B, int32_t h, int32_t w, lbm_stream_t stream) {
+  return encoder_tail_fused(f1, f1_plane, W1_hi, W1_lo, ldw1, b1, q2, q3, pos, tokens, B, h, w, (hipStream_t)stream, tokens_s, tokens_plane);
+}
+
 int lbm_hip_pack_fragment_major(const void* hi, const void* lo, int32_t N, int32_t K, void* out, lbm_stream_t stream) {
   return pack_fragment_major(hi, lo, N, K, out, (hipStream_t)stream);
 }

@@ -42,14 +42,30 @@ struct TailArgs {
   const float* q2;    // [B, (h/2)*(w/2), 256]
   const float* q3;    // [B, (h/4)*(w/4), 256]
   const float* pos;   // [h*w, 256] or null
+  // MODE 2: q1 is not read but formed here as f1 . W1^T + b1 (the 64 -> 256 product of the finest level, split operands)
+  const _Float16* f1;   // split planes [B, h*w, 64]
+  long long f1_plane;
+  const _Float16* w1h;  // [256, ldw1]
+  const _Float16* w1l;
+  int ldw1;
+  const float* b1;
 };
 
-template <bool TAIL>
+// MODE 0: pooling only; 1: TAIL (q1 from memory); 2: TAIL with q1 = f1 . W1^T + b1 computed by the workgroup (16 waves = 2 x 8
+// blocks of 32 cells x 32 channels, 12 MFMAs each, operands straight from memory into registers) and handed over through LDS: the
+// [B h w, 256] product is neither written nor read back (0.8 GB each way at 64 frames).  Same MFMA order and final combination as
+// gemm_ss: the tokens are bit-identical to MODE 1 fed by that kernel.
+template <int MODE>
 __global__ __launch_bounds__(1024) void pyramid_pool_kernel(float* __restrict__ tok, int B, int h, int w, int L, void* toks,
                                                             long long toks_plane, TailArgs ta) {
+  constexpr bool TAIL = MODE != 0;
+  constexpr int QP = 260;                       // pitch of the q1 block in LDS (floats): rows stay 16-byte aligned
+  // (the q1 block and the pooling's partial sums share LDS -- 66.5 KB, two workgroups per CU: with both resident, 82.5 KB, a CU held
+  // ONE workgroup and its load / multiply / pool / store phases ran back to back: 986 us instead of 823 + 236 at 64 frames)
+  __shared__ __attribute__((aligned(16))) float q1s[MODE == 2 ? 64 * QP : 16 * 64 * 4];
+  float4 (*part)[64] = reinterpret_cast<float4 (*)[64]>(q1s);
   // 16 waves per 8x8 block: wave q owns the 2x2 cells at (2 (q / 4), 2 (q % 4)) -- all of its loads are independent and
   // in flight together -- and produces their level-1 cell; the 2x2 sums meet in LDS for levels 2 (waves 0..3) and 3.
-  __shared__ float4 part[16][64];
   const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int bw = w >> 3, bh = h >> 3;
   const int P0 = h * w;
@@ -60,6 +76,36 @@ __global__ __launch_bounds__(1024) void pyramid_pool_kernel(float* __restrict__ 
   float* base = tok + (long long)b * L * LBM_C + lane * 4;
   const long long sbase = (long long)b * L * LBM_C + lane * 4;
   float4 v[2][2];
+  if constexpr (MODE == 2) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int r = lane & 31, hh = lane >> 5, rb = q >> 3, cbk = q & 7;
+    const int c = 32 * rb + r;                                          // cell of the 8 x 8 block, row-major
+    const long long row = (long long)b * P0 + (long long)(by * 8 + (c >> 3)) * w + bx * 8 + (c & 7);
+    const _Float16* ap = ta.f1 + row * 64 + 8 * hh;
+    const long long wo = (long long)(32 * cbk + r) * ta.ldw1 + 8 * hh;
+    half8 ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      ah[ks] = *reinterpret_cast<const half8*>(ap + ks * 16);
+      al[ks] = *reinterpret_cast<const half8*>(ap + ta.f1_plane + ks * 16);
+      bh[ks] = *reinterpret_cast<const half8*>(ta.w1h + wo + ks * 16);
+      bl[ks] = *reinterpret_cast<const half8*>(ta.w1l + wo + ks * 16);
+    }
+    const float bv = ta.b1 ? ta.b1[32 * cbk + r] : 0.f;
+    f32x16 acc, acx;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = acx[e] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bh[ks], acc, 0, 0, 0);
+      acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bl[ks], acx, 0, 0, 0);
+      acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], bh[ks], acx, 0, 0, 0);
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) q1s[(32 * rb + 4 * hh + (e & 3) + 8 * (e >> 2)) * QP + 32 * cbk + r] = (acc[e] + acx[e] * (1.0f / 2048.0f)) + bv;
+    __syncthreads();
+#endif
+  }
   if constexpr (!TAIL) {
 #pragma unroll
     for (int dy = 0; dy < 2; ++dy)
@@ -93,7 +139,9 @@ __global__ __launch_bounds__(1024) void pyramid_pool_kernel(float* __restrict__ 
         up_coeff(x0 + dx, 1, w2, xa, xb, lxa, lxb);
         up_coeff(x0 + dx, 2, w4, xc, xd, lxc, lxd);
         const long long cell = (long long)(y0 + dy) * w + x0 + dx;
-        const float4 a1 = ld4(q1 + cell * LBM_C);
+        float4 a1;
+        if constexpr (MODE == 2) a1 = *reinterpret_cast<const float4*>(q1s + ((y0 + dy - by * 8) * 8 + (x0 + dx - bx * 8)) * QP + lane * 4);
+        else a1 = ld4(q1 + cell * LBM_C);
         const float4 a2 = bil(q2, w2, ya, yb, xa, xb, lya, lyb, lxa, lxb);
         const float4 a3 = bil(q3, w4, yc, yd, xc, xd, lyc, lyd, lxc, lxd);
         float4 t = make_float4(gelu_erf(a1.x + a2.x + a3.x), gelu_erf(a1.y + a2.y + a3.y), gelu_erf(a1.z + a2.z + a3.z),
@@ -123,6 +171,7 @@ __global__ __launch_bounds__(1024) void pyramid_pool_kernel(float* __restrict__ 
   // level 1: this wave's 2x2 window, row-major
   const float4 s4 = add(add(add(v[0][0], v[0][1]), v[1][0]), v[1][1]);
   put(P0 + (long long)(y0 >> 1) * w1 + (x0 >> 1), mul(s4, 0.25f));
+  if constexpr (MODE == 2) __syncthreads();      // every wave has read its cells of the q1 block: the space is the partial sums' now
   part[q][lane] = s4;
   __syncthreads();
   if (q < 4) {
@@ -147,7 +196,7 @@ int pyramid_pool(float* tokens, int B, int h, int w, hipStream_t stream, void* t
   const long long blocks = (long long)B * (h / 8) * (w / 8);
   LBM_REQUIRE(blocks < 0x7fffffffLL, "pyramid_pool: too many blocks");
   ProfScope prof("pyramid_pool", stream, 0.0, 4.0 * LBM_C * B * ((double)P0 + (L - P0)) * (toks ? 2.0 : 1.0));
-  hipLaunchKernelGGL(pyramid_pool_kernel<false>, dim3((unsigned)blocks), dim3(1024), 0, stream, tokens, B, h, w, L, toks, toks_plane,
+  hipLaunchKernelGGL(pyramid_pool_kernel<0>, dim3((unsigned)blocks), dim3(1024), 0, stream, tokens, B, h, w, L, toks, toks_plane,
                      TailArgs{});
   return check_launch("pyramid_pool");
 }
@@ -160,9 +209,30 @@ int encoder_tail(const float* q1, const float* q2, const float* q3, const float*
   const long long blocks = (long long)B * (h / 8) * (w / 8);
   LBM_REQUIRE(blocks < 0x7fffffffLL, "encoder_tail: too many blocks");
   ProfScope prof("encoder_tail", stream, 0.0, 4.0 * LBM_C * B * ((double)P0 * (1.0 + 0.25 + 0.0625 + (pos ? 1.0 : 0.0)) + (double)L * (toks ? 2.0 : 1.0)));
-  TailArgs ta{q1, q2, q3, pos};
-  hipLaunchKernelGGL(pyramid_pool_kernel<true>, dim3((unsigned)blocks), dim3(1024), 0, stream, tokens, B, h, w, L, toks, toks_plane, ta);
+  TailArgs ta{};
+  ta.q1 = q1; ta.q2 = q2; ta.q3 = q3; ta.pos = pos;
+  hipLaunchKernelGGL(pyramid_pool_kernel<1>, dim3((unsigned)blocks), dim3(1024), 0, stream, tokens, B, h, w, L, toks, toks_plane, ta);
   return check_launch("encoder_tail");
+}
+
+// encoder_tail with the finest level's 64 -> 256 product inside: f1 split planes [B, h*w, 64], W1 split [256, ldw1], b1 [256] or null
+int encoder_tail_fused(const void* f1, long long f1_plane, const void* w1h, const void* w1l, int ldw1, const float* b1, const float* q2,
+                       const float* q3, const float* pos, float* tokens, int B, int h, int w, hipStream_t stream, void* toks,
+                       long long toks_plane) {
+  LBM_REQUIRE(f1 && w1h && w1l && q2 && q3 && tokens && B > 0 && h % 8 == 0 && w % 8 == 0, "encoder_tail_fused: bad arguments (grid %dx%d)", h, w);
+  LBM_REQUIRE(((uintptr_t)f1 & 15) == 0 && f1_plane % 8 == 0 && ((uintptr_t)w1h & 15) == 0 && ((uintptr_t)w1l & 15) == 0 && ldw1 >= 64 && ldw1 % 8 == 0,
+              "encoder_tail_fused: operands must be 16-byte aligned, weight rows >= 64 columns");
+  const int P0 = h * w;
+  const int L = P0 + P0 / 4 + P0 / 16 + P0 / 64;
+  const long long blocks = (long long)B * (h / 8) * (w / 8);
+  LBM_REQUIRE(blocks < 0x7fffffffLL, "encoder_tail_fused: too many blocks");
+  ProfScope prof("encoder_tail", stream, 2.0 * B * P0 * 256.0 * 64.0,
+                 4.0 * LBM_C * B * ((double)P0 * (0.25 + 0.25 + 0.0625 + (pos ? 1.0 : 0.0)) + (double)L * (toks ? 2.0 : 1.0)));
+  TailArgs ta{};
+  ta.q2 = q2; ta.q3 = q3; ta.pos = pos;
+  ta.f1 = (const _Float16*)f1; ta.f1_plane = f1_plane; ta.w1h = (const _Float16*)w1h; ta.w1l = (const _Float16*)w1l; ta.ldw1 = ldw1; ta.b1 = b1;
+  hipLaunchKernelGGL(pyramid_pool_kernel<2>, dim3((unsigned)blocks), dim3(1024), 0, stream, tokens, B, h, w, L, toks, toks_plane, ta);
+  return check_launch("encoder_tail_fused");
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -18,6 +18,9 @@ int topk_rows(const float* corr, long long ld, int P, int k, int rows, int grid_
 
 int encoder_tail(const float* q1, const float* q2, const float* q3, const float* pos, float* tokens, int B, int h, int w,
                  hipStream_t stream, void* toks = nullptr, long long toks_plane = 0);
+int encoder_tail_fused(const void* f1, long long f1_plane, const void* w1h, const void* w1l, int ldw1, const float* b1, const float* q2,
+                       const float* q3, const float* pos, float* tokens, int B, int h, int w, hipStream_t stream, void* toks = nullptr,
+                       long long toks_plane = 0);
 int topk_candidates(const float* cand_v, const int* cand_i, int n_cand, int P, int k, int rows, int grid_w, int stride_px, int* idx_out,
                     float* ref_out, float* val_out, hipStream_t stream);
 void topk_force_mode(int m);   // tuning: 1 = the per-lane-list kernels for every shape

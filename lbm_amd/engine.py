@@ -193,7 +193,9 @@ class EncoderWeights:
             y, ys = c2.split(ts, True, idn, want_f32=nxt is not None and nxt[2] is None, scratch=self._scratch, planes=self.planes)
             if i % 2 == 1:
                 feats.append(ys)
-        qs = [hip.linear_ss(f.reshape(-1, f.shape[-1]), wt, self.lvl_b if i == 0 else None, planes=self.planes)[0]
+        fused_q1 = self.planes == 2 and os.environ.get("LBM_AMD_FUSED_Q1", "1") != "0"     # level-0 product inside the tail kernel
+        qs = [None if (i == 0 and fused_q1) else
+              hip.linear_ss(f.reshape(-1, f.shape[-1]), wt, self.lvl_b if i == 0 else None, planes=self.planes)[0]
               for i, (f, wt) in enumerate(zip(feats, self.lvl_ws))]
         if out is None:
             out = torch.empty(B, self.L, 256, device=self.dev, dtype=torch.float32)
@@ -203,7 +205,11 @@ class EncoderWeights:
                 self._own_split = hip.SplitTensor((B, self.L, 256), self.dev)
             target = self._own_split
         self.tokens_split = target
-        hip.encoder_tail(qs[0], qs[1], qs[2], self.pos if add_pos else None, out, target, self.h, self.w)
+        if fused_q1:
+            hip.encoder_tail_fused(feats[0], self.lvl_ws[0], self.lvl_b, qs[1], qs[2], self.pos if add_pos else None, out, target,
+                                   self.h, self.w)
+        else:
+            hip.encoder_tail(qs[0], qs[1], qs[2], self.pos if add_pos else None, out, target, self.h, self.w)
         return out
 
 

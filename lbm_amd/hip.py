@@ -30,6 +30,7 @@ EXPORTS = (
     "lbm_hip_update_points", "lbm_hip_encoder_tail", "lbm_hip_pack_fragment_major", "lbm_hip_ffn_slabs",
     "lbm_hip_debug_ptr", "lbm_hip_update_points_static", "lbm_hip_preprocess_u8", "lbm_hip_corr_topk",
     "lbm_hip_corr_topk_workspace_bytes", "lbm_hip_preprocess_split", "lbm_hip_stem_pool",
+    "lbm_hip_encoder_tail_fused",
 )
 
 
@@ -164,6 +165,8 @@ def load() -> C.CDLL:
     lib.lbm_hip_preprocess_split.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_int64] + [C.c_int32] * 5 + [C.c_void_p]
     lib.lbm_hip_stem_pool.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                       C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    lib.lbm_hip_encoder_tail_fused.argtypes = ([C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32] + [C.c_void_p] * 6 + [C.c_int64] +
+                                               [C.c_int32] * 3 + [C.c_void_p])
     lib.lbm_hip_corr_topk_workspace_bytes.restype = C.c_int64
     lib.lbm_hip_corr_topk_workspace_bytes.argtypes = [C.c_int32] * 4
     lib.lbm_hip_corr_topk.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
@@ -378,6 +381,17 @@ def encoder_tail(q1: torch.Tensor, q2: torch.Tensor, q3: torch.Tensor, pos: Opti
     _check(load().lbm_hip_encoder_tail(_p(q1), _p(q2), _p(q3), _p(pos), _p(tokens), tokens_s.hi if tokens_s is not None else None,
                                        tokens_s.plane if tokens_s is not None else 0, tokens.shape[0], h, w, _stream()),
            "lbm_hip_encoder_tail")
+
+
+def encoder_tail_fused(f1: "SplitTensor", w1: "SplitWeight", b1: Optional[torch.Tensor], q2: torch.Tensor, q3: torch.Tensor,
+                       pos: Optional[torch.Tensor], tokens: torch.Tensor, tokens_s: Optional["SplitTensor"], h: int, w: int) -> None:
+    """encoder_tail with q1 = f1 . w1^T + b1 formed inside the kernel (lbm_hip_encoder_tail_fused); f1: split (B, h, w, 64)."""
+    _require_gpu()
+    assert w1.shape == (256, 64) and f1.shape[-1] == 64
+    _check(load().lbm_hip_encoder_tail_fused(f1.hi, f1.plane, w1.hi, w1.lo, 64, _p(b1), _p(q2), _p(q3), _p(pos), _p(tokens),
+                                             tokens_s.hi if tokens_s is not None else None,
+                                             tokens_s.plane if tokens_s is not None else 0, tokens.shape[0], h, w, _stream()),
+           "lbm_hip_encoder_tail_fused")
 
 
 def pyramid_s(tokens: torch.Tensor, tokens_s: "SplitTensor", h: int, w: int) -> None:

@@ -210,3 +210,30 @@ def test_preprocess_split_is_the_split_of_preprocess(hip):
         assert torch.equal(got.planes.view(torch.int16), want.planes.view(torch.int16))
     hwc = frames.permute(0, 2, 3, 1).contiguous()
     assert torch.equal(hip.preprocess_split(hwc.flip(-1).contiguous(), 48, 64, "hwc_bgr").planes.view(torch.int16), want.planes.view(torch.int16))
+
+
+@pytest.mark.parametrize("B,h,w,with_pos", [(1, 8, 8, True), (2, 16, 24, False), (1, 96, 128, True)])
+def test_encoder_tail_with_the_level0_product_inside_is_bit_identical(hip, B, h, w, with_pos):
+    """lbm_hip_encoder_tail_fused (q1 = f1 . W1^T + b1 formed per 8 x 8 block on the matrix cores) against lbm_hip_linear_ss followed
+    by lbm_hip_encoder_tail: tokens of all four levels and their split twin, bit for bit."""
+    g = torch.Generator(device="cpu").manual_seed(h * w + B)
+    P0 = h * w
+    L = P0 + P0 // 4 + P0 // 16 + P0 // 64
+    f1 = hip.split_tensor(torch.randn(B, h, w, 64, generator=g).cuda())
+    w1 = hip.SplitWeight((torch.randn(256, 64, generator=g) * 0.2).cuda())
+    b1 = torch.randn(256, generator=g).cuda()
+    q2 = torch.randn(B, P0 // 4, 256, generator=g).cuda()
+    q3 = torch.randn(B, P0 // 16, 256, generator=g).cuda()
+    pos = torch.randn(P0, 256, generator=g).cuda() if with_pos else None
+    outs = []
+    for fused in (False, True):
+        tok = torch.zeros(B, L, 256, device="cuda")
+        toks = hip.SplitTensor((B, L, 256), "cuda")
+        if fused:
+            hip.encoder_tail_fused(f1, w1, b1, q2, q3, pos, tok, toks, h, w)
+        else:
+            q1 = hip.linear_ss(f1.reshape(-1, 64), w1, b1)[0]
+            hip.encoder_tail(q1, q2, q3, pos, tok, toks, h, w)
+        outs.append((tok, toks))
+    assert torch.equal(outs[0][0].view(torch.int32), outs[1][0].view(torch.int32))
+    assert torch.equal(outs[0][1].planes.view(torch.int16), outs[1][1].planes.view(torch.int16))

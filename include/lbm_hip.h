@@ -337,6 +337,9 @@ typedef struct {
    * either way).  NULL: computed every frame into the workspace.                                                  */
   float* query_u0;
   int32_t query_u0_valid;
+  /* optional: inv_norm [B, L] fp32 = 1 / max(|tokens row|, 1e-12) (F.normalize's factor, transformer.py:207) as written by
+   * lbm_hip_encoder_tail_fused for exactly these tokens: the step then skips its own norm pass.  NULL: computed here.        */
+  const float* inv_norm;
 } lbm_hip_step_desc;
 
 /* Tail of the encoder (backbone.py:53-65, 181-193 and transformer.py:58-69 in one pass): the 1x1 projections, the
@@ -348,10 +351,11 @@ int lbm_hip_encoder_tail(const float* q1, const float* q2, const float* q3, cons
                          int64_t tokens_plane, int32_t B, int32_t h, int32_t w, lbm_stream_t stream);
 /* The same with the finest level's product inside: q1 = f1 . W1^T + b1 is formed per 8 x 8 block of cells on the matrix cores
  * (f1: split planes [B, h*w, 64] of the layer-1 features, W1_hi / W1_lo: [256, ldw1] split weights of (fusion o proj1), b1 [256] or
- * NULL) and never reaches memory.  Bit-identical tokens to lbm_hip_linear_ss + lbm_hip_encoder_tail.                          */
+ * NULL) and never reaches memory.  Bit-identical tokens to lbm_hip_linear_ss + lbm_hip_encoder_tail.  inv_norm (optional) [B, L]:
+ * receives 1 / max(|row|, 1e-12) of every token row written, for lbm_hip_step_desc.inv_norm.                                   */
 int lbm_hip_encoder_tail_fused(const void* f1, int64_t f1_plane, const void* W1_hi, const void* W1_lo, int32_t ldw1, const float* b1,
                                const float* q2, const float* q3, const float* pos, float* tokens, void* tokens_s, int64_t tokens_plane,
-                               int32_t B, int32_t h, int32_t w, lbm_stream_t stream);
+                               float* inv_norm, int32_t B, int32_t h, int32_t w, lbm_stream_t stream);
 
 /* Fragment-major copy of a split weight matrix [N, K] (N % 32 == 0, K % 16 == 0): out[N/32][K/16][2][64][8] f16 -- for every
  * (32-row block, 16-deep k step) the 64 lanes' MFMA operand fragments of the hi plane, then of the lo plane, contiguous, so

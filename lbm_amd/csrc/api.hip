@@ -489,7 +489,9 @@ struct Step {
       }
     }
     if (linear(tok, LBM_C, hb + LBM_W_HEAD_VPROJ_W, hb + LBM_W_HEAD_VPROJ_B, value, nv, (int)BL, nv, LBM_C)) return -1;
-    return corr_maps(d->tokens, buf<float>("inv_norm"), buf<float>("corr_maps"), d->corr_mix, d->n_layers, d->B, h, w, split, s);
+    // (row norms handed over by the encoder tail: the norm kernel is skipped)
+    return corr_maps(d->tokens, d->inv_norm ? const_cast<float*>(d->inv_norm) : buf<float>("inv_norm"), buf<float>("corr_maps"), d->corr_mix,
+                     d->n_layers, d->B, h, w, split, s, d->inv_norm != nullptr);
   }
 
   // ---- everything that depends on the points, for rows [lo, lo + R) ----
@@ -980,8 +982,9 @@ int lbm_hip_encoder_tail(const float* q1, const float* q2, const float* q3, cons
 
 int lbm_hip_encoder_tail_fused(const void* f1, int64_t f1_plane, const void* W1_hi, const void* W1_lo, int32_t ldw1, const float* b1,
                                const float* q2, const float* q3, const float* pos, float* tokens, void* tokens_s, int64_t tokens_plane,
-                               int32_t B, int32_t h, int32_t w, lbm_stream_t stream) {
-  return encoder_tail_fused(f1, f1_plane, W1_hi, W1_lo, ldw1, b1, q2, q3, pos, tokens, B, h, w, (hipStream_t)stream, tokens_s, tokens_plane);
+                               float* inv_norm, int32_t B, int32_t h, int32_t w, lbm_stream_t stream) {
+  return encoder_tail_fused(f1, f1_plane, W1_hi, W1_lo, ldw1, b1, q2, q3, pos, tokens, B, h, w, (hipStream_t)stream, tokens_s, tokens_plane,
+                            inv_norm);
 }
 
 int lbm_hip_pack_fragment_major(const void* hi, const void* lo, int32_t N, int32_t K, void* out, lbm_stream_t stream) {

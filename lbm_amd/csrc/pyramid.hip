@@ -49,7 +49,15 @@ struct TailArgs {
   const _Float16* w1l;
   int ldw1;
   const float* b1;
+  float* inv;           // [B, L] or null: 1 / max(|row|, 1e-12) of every token row written here (what corr_maps would compute)
 };
+
+// F.normalize's factor for one 256-channel row held by a wave (lane = 4 channels); every rounding spelled out: the encoder tail and
+// inv_norm_kernel must give the same bits
+__device__ __forceinline__ float row_inv_norm(const float4 x) {
+  const float ss = __fmaf_rn(x.w, x.w, __fmaf_rn(x.z, x.z, __fmaf_rn(x.y, x.y, __fmul_rn(x.x, x.x))));
+  return __fdiv_rn(1.0f, fmaxf(sqrtf(wave_sum(ss)), 1e-12f));     // F.normalize eps
+}
 
 // MODE 0: pooling only; 1: TAIL (q1 from memory); 2: TAIL with q1 = f1 . W1^T + b1 computed by the workgroup (16 waves = 2 x 8
 // blocks of 32 cells x 32 channels, 12 MFMAs each, operands straight from memory into registers) and handed over through LDS: the
@@ -152,6 +160,10 @@ __global__ __launch_bounds__(1024) void pyramid_pool_kernel(float* __restrict__ 
         }
         v[dy][dx] = t;
         st4(base + cell * LBM_C, t);
+        if (ta.inv) {
+          const float sn = row_inv_norm(t);
+          if (lane == 0) ta.inv[(long long)b * L + cell] = sn;
+        }
       }
     }
   }
@@ -166,6 +178,12 @@ __global__ __launch_bounds__(1024) void pyramid_pool_kernel(float* __restrict__ 
   auto put = [&](long long cell, const float4 o) {
     st4(base + cell * LBM_C, o);
     if (toks) st4_split(toks, toks_plane, sbase + cell * LBM_C, o);
+    if constexpr (TAIL) {
+      if (ta.inv) {
+        const float sn = row_inv_norm(o);
+        if (lane == 0) ta.inv[(long long)b * L + cell] = sn;
+      }
+    }
   };
   const int w1 = w >> 1, w2l = w >> 2, w3 = w >> 3;
   // level 1: this wave's 2x2 window, row-major
@@ -218,7 +236,7 @@ int encoder_tail(const float* q1, const float* q2, const float* q3, const float*
 // encoder_tail with the finest level's 64 -> 256 product inside: f1 split planes [B, h*w, 64], W1 split [256, ldw1], b1 [256] or null
 int encoder_tail_fused(const void* f1, long long f1_plane, const void* w1h, const void* w1l, int ldw1, const float* b1, const float* q2,
                        const float* q3, const float* pos, float* tokens, int B, int h, int w, hipStream_t stream, void* toks,
-                       long long toks_plane) {
+                       long long toks_plane, float* inv_norm) {
   LBM_REQUIRE(f1 && w1h && w1l && q2 && q3 && tokens && B > 0 && h % 8 == 0 && w % 8 == 0, "encoder_tail_fused: bad arguments (grid %dx%d)", h, w);
   LBM_REQUIRE(((uintptr_t)f1 & 15) == 0 && f1_plane % 8 == 0 && ((uintptr_t)w1h & 15) == 0 && ((uintptr_t)w1l & 15) == 0 && ldw1 >= 64 && ldw1 % 8 == 0,
               "encoder_tail_fused: operands must be 16-byte aligned, weight rows >= 64 columns");
@@ -230,7 +248,7 @@ int encoder_tail_fused(const void* f1, long long f1_plane, const void* w1h, cons
                  4.0 * LBM_C * B * ((double)P0 * (0.25 + 0.25 + 0.0625 + (pos ? 1.0 : 0.0)) + (double)L * (toks ? 2.0 : 1.0)));
   TailArgs ta{};
   ta.q2 = q2; ta.q3 = q3; ta.pos = pos;
-  ta.f1 = (const _Float16*)f1; ta.f1_plane = f1_plane; ta.w1h = (const _Float16*)w1h; ta.w1l = (const _Float16*)w1l; ta.ldw1 = ldw1; ta.b1 = b1;
+  ta.f1 = (const _Float16*)f1; ta.f1_plane = f1_plane; ta.w1h = (const _Float16*)w1h; ta.w1l = (const _Float16*)w1l; ta.ldw1 = ldw1; ta.b1 = b1; ta.inv = inv_norm;
   hipLaunchKernelGGL(pyramid_pool_kernel<2>, dim3((unsigned)blocks), dim3(1024), 0, stream, tokens, B, h, w, L, toks, toks_plane, ta);
   return check_launch("encoder_tail_fused");
 }
@@ -239,9 +257,8 @@ int encoder_tail_fused(const void* f1, long long f1_plane, const void* w1h, cons
 __global__ __launch_bounds__(256) void inv_norm_kernel(const float* __restrict__ tok, float* __restrict__ inv, long long rows) {
   const int lane = threadIdx.x & 63;
   for (long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long long)gridDim.x * 4) {
-    const float4 x = ld4(tok + row * LBM_C + lane * 4);
-    const float n = sqrtf(wave_sum(x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w));
-    if (lane == 0) inv[row] = 1.0f / fmaxf(n, 1e-12f);     // F.normalize eps
+    const float sn = row_inv_norm(ld4(tok + row * LBM_C + lane * 4));
+    if (lane == 0) inv[row] = sn;
   }
 }
 
@@ -308,7 +325,7 @@ float* g_corr_trace = nullptr;   // lbm_hip_debug_ptr key 1
 int g_corr_skip_norm = 0;        // debug key 10: 1 = the caller's inv_norm buffer is used as it is (scripts/stale_offline.py)
 
 int corr_maps(const float* tokens, float* inv_norm, float* F, const float* wmix_host, int n_layers, int B, int h, int w,
-              bool split, hipStream_t stream) {
+              bool split, hipStream_t stream, bool have_norm) {
   LBM_REQUIRE(tokens && inv_norm && F && wmix_host, "corr_maps: null argument");
   LBM_REQUIRE(n_layers >= 1 && n_layers <= 8, "corr_maps: n_layers=%d out of range", n_layers);
   LBM_REQUIRE(B > 0 && h % 8 == 0 && w % 8 == 0, "corr_maps: grid %dx%d must be a multiple of 8", h, w);
@@ -317,7 +334,7 @@ int corr_maps(const float* tokens, float* inv_norm, float* F, const float* wmix_
   long long rows = (long long)B * L;
   long long blocks = (rows + 3) / 4;
   if (blocks > 16384) blocks = 16384;
-  if (!g_corr_skip_norm) {
+  if (!g_corr_skip_norm && !have_norm) {
     ProfScope prof("inv_norm", stream, 0.0, 4.0 * LBM_C * rows);
     hipLaunchKernelGGL(inv_norm_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, tokens, inv_norm, rows);
   }

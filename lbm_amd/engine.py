@@ -206,9 +206,13 @@ class EncoderWeights:
             target = self._own_split
         self.tokens_split = target
         if fused_q1:
+            # the tail also leaves F.normalize's factor of every token row beside the split twin (engine.step hands it to the step)
+            if target.inv_norm is None or target.inv_norm.shape != (B, self.L):
+                target.inv_norm = torch.empty(B, self.L, device=self.dev, dtype=torch.float32)
             hip.encoder_tail_fused(feats[0], self.lvl_ws[0], self.lvl_b, qs[1], qs[2], self.pos if add_pos else None, out, target,
-                                   self.h, self.w)
+                                   self.h, self.w, target.inv_norm)
         else:
+            target.inv_norm = None
             hip.encoder_tail(qs[0], qs[1], qs[2], self.pos if add_pos else None, out, target, self.h, self.w)
         return out
 
@@ -451,10 +455,13 @@ class TrackEngine:
         d.ring_head, d.update_state = ring_head, 1 if update_state else 0
         ih, iw = img_hw if img_hw is not None else cfg.input_size
         d.img_h, d.img_w = float(ih), float(iw)
+        d.inv_norm = None
         if tokens_split is not None and d.precision >= 1:
             if tokens_split.shape != tuple(tokens.shape):
                 raise hip.HipError("tokens_split does not match tokens")
             d.tokens_split = tokens_split.hi
+            inv = getattr(tokens_split, "inv_norm", None)
+            d.inv_norm = inv.data_ptr() if inv is not None and os.environ.get("LBM_AMD_TAIL_NORMS", "1") != "0" else None
         ws = self.workspace(d, ws_slot)
         dev = self.dev
         d.phase, d.sub_index = phase, sub_index

@@ -87,7 +87,7 @@ class StepDesc(C.Structure):
                 ("aux_streams", C.c_void_p * 3), ("n_aux_streams", C.c_int32),
                 ("phase", C.c_int32), ("row_lo", C.c_int32), ("row_count", C.c_int32), ("sub_index", C.c_int32),
                 ("query_split", C.c_void_p), ("vis_flag", C.c_void_p), ("rho_prob", C.c_void_p),
-                ("query_u0", C.c_void_p), ("query_u0_valid", C.c_int32)]
+                ("query_u0", C.c_void_p), ("query_u0_valid", C.c_int32), ("inv_norm", C.c_void_p)]
 
 
 class ProfileEntry(C.Structure):
@@ -166,7 +166,7 @@ def load() -> C.CDLL:
     lib.lbm_hip_stem_pool.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                       C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     lib.lbm_hip_encoder_tail_fused.argtypes = ([C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32] + [C.c_void_p] * 6 + [C.c_int64] +
-                                               [C.c_int32] * 3 + [C.c_void_p])
+                                               [C.c_void_p] + [C.c_int32] * 3 + [C.c_void_p])
     lib.lbm_hip_corr_topk_workspace_bytes.restype = C.c_int64
     lib.lbm_hip_corr_topk_workspace_bytes.argtypes = [C.c_int32] * 4
     lib.lbm_hip_corr_topk.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
@@ -246,6 +246,8 @@ class SplitWeight:
 
 class SplitTensor:
     """An activation stored as two f16 planes (hi, lo * 2^11): `planes` has shape (2, *shape)."""
+
+    inv_norm: Optional[torch.Tensor] = None     # (B, L) row factors of F.normalize, when the producer of the twin also wrote them
 
     def __init__(self, shape, device):
         self.shape = tuple(shape)
@@ -384,13 +386,16 @@ def encoder_tail(q1: torch.Tensor, q2: torch.Tensor, q3: torch.Tensor, pos: Opti
 
 
 def encoder_tail_fused(f1: "SplitTensor", w1: "SplitWeight", b1: Optional[torch.Tensor], q2: torch.Tensor, q3: torch.Tensor,
-                       pos: Optional[torch.Tensor], tokens: torch.Tensor, tokens_s: Optional["SplitTensor"], h: int, w: int) -> None:
-    """encoder_tail with q1 = f1 . w1^T + b1 formed inside the kernel (lbm_hip_encoder_tail_fused); f1: split (B, h, w, 64)."""
+                       pos: Optional[torch.Tensor], tokens: torch.Tensor, tokens_s: Optional["SplitTensor"], h: int, w: int,
+                       inv_norm: Optional[torch.Tensor] = None) -> None:
+    """encoder_tail with q1 = f1 . w1^T + b1 formed inside the kernel (lbm_hip_encoder_tail_fused); f1: split (B, h, w, 64).
+    inv_norm (B, L): receives F.normalize's factor of every token row (the step's correlation maps then skip their norm pass)."""
     _require_gpu()
     assert w1.shape == (256, 64) and f1.shape[-1] == 64
+    assert inv_norm is None or (inv_norm.shape == tuple(tokens.shape[:2]) and inv_norm.is_contiguous())
     _check(load().lbm_hip_encoder_tail_fused(f1.hi, f1.plane, w1.hi, w1.lo, 64, _p(b1), _p(q2), _p(q3), _p(pos), _p(tokens),
                                              tokens_s.hi if tokens_s is not None else None,
-                                             tokens_s.plane if tokens_s is not None else 0, tokens.shape[0], h, w, _stream()),
+                                             tokens_s.plane if tokens_s is not None else 0, _p(inv_norm), tokens.shape[0], h, w, _stream()),
            "lbm_hip_encoder_tail_fused")
 
 

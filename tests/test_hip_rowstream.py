@@ -4,6 +4,8 @@ Linear form: bit-identical to the tiled product (gemm16.hip) on every output kin
 Correlation + top-k form (lbm_hip_corr_topk; transformer.py:306-308, coord_utils.py:4-29): the selected cells, their order,
 scores and centres equal the dense product followed by the dense top-k, bit for bit; exact ties go to the lowest cell
 wherever in the partition (other half-wave, other step, other cell range) the equal cells lie."""
+import ctypes as C
+
 import numpy as np
 import pytest
 import torch
@@ -237,3 +239,27 @@ def test_encoder_tail_with_the_level0_product_inside_is_bit_identical(hip, B, h,
         outs.append((tok, toks))
     assert torch.equal(outs[0][0].view(torch.int32), outs[1][0].view(torch.int32))
     assert torch.equal(outs[0][1].planes.view(torch.int16), outs[1][1].planes.view(torch.int16))
+
+
+def test_encoder_tail_row_norms_are_the_norm_kernels(hip):
+    """The row factors lbm_hip_encoder_tail_fused leaves beside the tokens equal, bit for bit, what the step's own norm pass computes
+    (lbm_hip_corr_maps writes them into its inv_norm argument)."""
+    B, h, w = 2, 16, 24
+    g = torch.Generator(device="cpu").manual_seed(3)
+    P0 = h * w
+    L = P0 + P0 // 4 + P0 // 16 + P0 // 64
+    f1 = hip.split_tensor(torch.randn(B, h, w, 64, generator=g).cuda())
+    w1 = hip.SplitWeight((torch.randn(256, 64, generator=g) * 0.2).cuda())
+    q2 = torch.randn(B, P0 // 4, 256, generator=g).cuda()
+    q3 = torch.randn(B, P0 // 16, 256, generator=g).cuda()
+    tok = torch.zeros(B, L, 256, device="cuda")
+    inv = torch.zeros(B, L, device="cuda")
+    hip.encoder_tail_fused(f1, w1, None, q2, q3, None, tok, None, h, w, inv)
+    inv2 = torch.zeros(B, L, device="cuda")
+    F = torch.empty(1, B, P0, 256, device="cuda")
+    mix = (C.c_float * 4)(0.1, 0.2, 0.3, 0.4)
+    assert hip.load().lbm_hip_corr_maps(tok.data_ptr(), inv2.data_ptr(), F.data_ptr(), mix, 1, B, h, w, None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(inv.view(torch.int32), inv2.view(torch.int32))
+    want = 1.0 / tok.double().norm(dim=-1).clamp_min(1e-12)
+    assert float(((inv.double() - want) / want).abs().max()) < 1e-6

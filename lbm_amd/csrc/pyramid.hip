@@ -63,10 +63,14 @@ __device__ __forceinline__ float row_inv_norm(const float4 x) {
 // blocks of 32 cells x 32 channels, 12 MFMAs each, operands straight from memory into registers) and handed over through LDS: the
 // [B h w, 256] product is neither written nor read back (0.8 GB each way at 64 frames).  Same MFMA order and final combination as
 // gemm_ss: the tokens are bit-identical to MODE 1 fed by that kernel.
-template <int MODE>
-__global__ __launch_bounds__(1024) void pyramid_pool_kernel(float* __restrict__ tok, int B, int h, int w, int L, void* toks,
+// With many blocks MODE 2 runs with NW = 8 waves per workgroup (each wave takes two of the sixteen 2 x 2 groups and two of the sixteen
+// MFMA blocks in turn): at ~94 VGPRs a 16-wave workgroup is alone on its CU and its load / multiply / pool / store phases run back to back; two
+// 8-wave workgroups per CU overlap them (1027 -> 922 us at 64 frames; one frame has fewer blocks than CUs and keeps 16 waves).
+template <int MODE, int NW = 16>
+__global__ __launch_bounds__(NW * 64) void pyramid_pool_kernel(float* __restrict__ tok, int B, int h, int w, int L, void* toks,
                                                             long long toks_plane, TailArgs ta) {
   constexpr bool TAIL = MODE != 0;
+  constexpr int GPW = 16 / NW;       // 2 x 2 groups (and MFMA blocks) per wave
   constexpr int QP = 260;                       // pitch of the q1 block in LDS (floats): rows stay 16-byte aligned
   // (the q1 block and the pooling's partial sums share LDS -- 66.5 KB, two workgroups per CU: with both resident, 82.5 KB, a CU held
   // ONE workgroup and its load / multiply / pool / store phases ran back to back: 986 us instead of 823 + 236 at 64 frames)
@@ -74,18 +78,19 @@ __global__ __launch_bounds__(1024) void pyramid_pool_kernel(float* __restrict__ 
   float4 (*part)[64] = reinterpret_cast<float4 (*)[64]>(q1s);
   // 16 waves per 8x8 block: wave q owns the 2x2 cells at (2 (q / 4), 2 (q % 4)) -- all of its loads are independent and
   // in flight together -- and produces their level-1 cell; the 2x2 sums meet in LDS for levels 2 (waves 0..3) and 3.
-  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int bw = w >> 3, bh = h >> 3;
   const int P0 = h * w;
   const int b = blockIdx.x / (bh * bw);
   const int rem = blockIdx.x - b * (bh * bw);
   const int by = rem / bw, bx = rem - by * bw;
-  const int y0 = by * 8 + (q >> 2) * 2, x0 = bx * 8 + (q & 3) * 2;
   float* base = tok + (long long)b * L * LBM_C + lane * 4;
   const long long sbase = (long long)b * L * LBM_C + lane * 4;
-  float4 v[2][2];
   if constexpr (MODE == 2) {
 #if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+   for (int gi = 0; gi < GPW; ++gi) {
+    const int q = wv + gi * NW;
     const int r = lane & 31, hh = lane >> 5, rb = q >> 3, cbk = q & 7;
     const int c = 32 * rb + r;                                          // cell of the 8 x 8 block, row-major
     const long long row = (long long)b * P0 + (long long)(by * 8 + (c >> 3)) * w + bx * 8 + (c & 7);
@@ -111,9 +116,29 @@ __global__ __launch_bounds__(1024) void pyramid_pool_kernel(float* __restrict__ 
     }
 #pragma unroll
     for (int e = 0; e < 16; ++e) q1s[(32 * rb + 4 * hh + (e & 3) + 8 * (e >> 2)) * QP + 32 * cbk + r] = (acc[e] + acx[e] * (1.0f / 2048.0f)) + bv;
+   }
     __syncthreads();
 #endif
   }
+  auto add = [](float4 a, const float4 c) { a.x += c.x; a.y += c.y; a.z += c.z; a.w += c.w; return a; };
+  auto mul = [](const float4 a, float f) { return make_float4(a.x * f, a.y * f, a.z * f, a.w * f); };
+  auto put = [&](long long cell, const float4 o) {
+    st4(base + cell * LBM_C, o);
+    if (toks) st4_split(toks, toks_plane, sbase + cell * LBM_C, o);
+    if constexpr (TAIL) {
+      if (ta.inv) {
+        const float sn = row_inv_norm(o);
+        if (lane == 0) ta.inv[(long long)b * L + cell] = sn;
+      }
+    }
+  };
+  const int w1 = w >> 1, w2l = w >> 2, w3 = w >> 3;
+  float4 s4g[GPW];
+#pragma unroll
+  for (int gi = 0; gi < GPW; ++gi) {
+  const int q = wv + gi * NW;
+  const int y0 = by * 8 + (q >> 2) * 2, x0 = bx * 8 + (q & 3) * 2;
+  float4 v[2][2];
   if constexpr (!TAIL) {
 #pragma unroll
     for (int dy = 0; dy < 2; ++dy)
@@ -173,25 +198,16 @@ __global__ __launch_bounds__(1024) void pyramid_pool_kernel(float* __restrict__ 
 #pragma unroll
       for (int dx = 0; dx < 2; ++dx) st4_split(toks, toks_plane, sbase + (long long)((y0 + dy) * w + x0 + dx) * LBM_C, v[dy][dx]);
   }
-  auto add = [](float4 a, const float4 c) { a.x += c.x; a.y += c.y; a.z += c.z; a.w += c.w; return a; };
-  auto mul = [](const float4 a, float f) { return make_float4(a.x * f, a.y * f, a.z * f, a.w * f); };
-  auto put = [&](long long cell, const float4 o) {
-    st4(base + cell * LBM_C, o);
-    if (toks) st4_split(toks, toks_plane, sbase + cell * LBM_C, o);
-    if constexpr (TAIL) {
-      if (ta.inv) {
-        const float sn = row_inv_norm(o);
-        if (lane == 0) ta.inv[(long long)b * L + cell] = sn;
-      }
-    }
-  };
-  const int w1 = w >> 1, w2l = w >> 2, w3 = w >> 3;
-  // level 1: this wave's 2x2 window, row-major
+  // level 1: this group's 2x2 window, row-major
   const float4 s4 = add(add(add(v[0][0], v[0][1]), v[1][0]), v[1][1]);
   put(P0 + (long long)(y0 >> 1) * w1 + (x0 >> 1), mul(s4, 0.25f));
+  s4g[gi] = s4;
+  }
   if constexpr (MODE == 2) __syncthreads();      // every wave has read its cells of the q1 block: the space is the partial sums' now
-  part[q][lane] = s4;
+#pragma unroll
+  for (int gi = 0; gi < GPW; ++gi) part[wv + gi * NW][lane] = s4g[gi];
   __syncthreads();
+  const int q = wv;
   if (q < 4) {
     // level 2: quadrant q = (q / 2, q % 2) of the block, the four 2x2 sums inside it
     const int qy = q >> 1, qx = q & 1;
@@ -249,7 +265,8 @@ int encoder_tail_fused(const void* f1, long long f1_plane, const void* w1h, cons
   TailArgs ta{};
   ta.q2 = q2; ta.q3 = q3; ta.pos = pos;
   ta.f1 = (const _Float16*)f1; ta.f1_plane = f1_plane; ta.w1h = (const _Float16*)w1h; ta.w1l = (const _Float16*)w1l; ta.ldw1 = ldw1; ta.b1 = b1; ta.inv = inv_norm;
-  hipLaunchKernelGGL(pyramid_pool_kernel<2>, dim3((unsigned)blocks), dim3(1024), 0, stream, tokens, B, h, w, L, toks, toks_plane, ta);
+  if (blocks >= 512) hipLaunchKernelGGL((pyramid_pool_kernel<2, 8>), dim3((unsigned)blocks), dim3(512), 0, stream, tokens, B, h, w, L, toks, toks_plane, ta);
+  else hipLaunchKernelGGL((pyramid_pool_kernel<2, 16>), dim3((unsigned)blocks), dim3(1024), 0, stream, tokens, B, h, w, L, toks, toks_plane, ta);
   return check_launch("encoder_tail_fused");
 }
 

@@ -976,3 +976,35 @@ def test_update_points_kernel_against_the_reference_edit(hip, N_old, N_new):
     q[:, upd] = new_q[:, upd]              # only the query: a re-planted surviving row keeps its memories (lbm_online.py:93-98)
     for a, b in zip(got, (q, st, co, vi, me)):
         assert torch.equal(a, b)
+
+
+def test_fused_encoder_stages_against_the_separate_kernels(hip, monkeypatch):
+    """The three encoder fusions of round 2 against the kernels they replace, switch by switch (LBM_AMD_FUSED_STEM: conv1 + relu +
+    max-pool in one launch -- same values up to the summation order inside the matrix cores; LBM_AMD_FUSED_Q1: the level-0 product
+    inside the tail kernel -- bit-identical; LBM_AMD_TAIL_NORMS: row norms handed to the step -- bit-identical tracks)."""
+    from lbm_amd.synth import synthetic_video, grid_queries
+    video = synthetic_video(4, 240, 320, seed=3).cuda()
+    pts = grid_queries(240, 320, 8).cuda()
+
+    def run(**env):
+        for k in ("LBM_AMD_FUSED_STEM", "LBM_AMD_FUSED_Q1", "LBM_AMD_TAIL_NORMS"):
+            monkeypatch.setenv(k, env.get(k, "1"))
+        model, _ = _online(dict(input_size=(96, 128), memory_size=4), precision="split")
+        with torch.no_grad():
+            tok = model.backbone.encode_tokens(video[0, :2]).clone()
+            model.init(pts, video[:, 0])
+            outs = [model.online_forward(video[:, t])[:3] for t in range(1, 4)]
+        return tok, outs
+
+    tok, outs = run()
+    tok_q1, outs_q1 = run(LBM_AMD_FUSED_Q1="0")
+    assert torch.equal(tok, tok_q1)
+    tok_n, outs_n = run(LBM_AMD_TAIL_NORMS="0")
+    assert torch.equal(tok, tok_n)
+    for a, b in zip(outs, outs_n):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    tok_s, outs_s = run(LBM_AMD_FUSED_STEM="0")
+    assert float((tok - tok_s).abs().max()) < 2e-5 * max(1.0, float(tok.abs().max()))
+    for a, b in zip(outs, outs_s):
+        assert float((a[0] - b[0]).abs().max()) < 0.02          # coordinates, frame pixels

@@ -317,6 +317,25 @@ def main():
             torch.cuda.synchronize()
             lat.append((time.perf_counter() - t1) * 1e3)
 
+        # the same with the frame step replayed as a HIP graph (LBM_online.use_graph, one graph per ring position): what a
+        # latency-bound caller would run; reported beside the eager figure, never instead of it
+        lat_graph = None
+        if world == 1 and getattr(r.model, "use_graph", None) is not None and not args.no_profile:
+            try:
+                r.model.use_graph = True
+                r.run(wl["M"] + 2)                    # first use of a ring position captures its graph
+                lg = []
+                for i in range(min(args.steps, 50)):
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    r.run(1, first=i)
+                    torch.cuda.synchronize()
+                    lg.append((time.perf_counter() - t1) * 1e3)
+                if r.model.use_graph:                  # (a failed capture switches the model back to eager launches)
+                    lat_graph = statistics.median(lg)
+            finally:
+                r.model.use_graph = False
+
         # per-kernel HIP-event timing of the same step (separate pass so the events do not perturb `elapsed`)
         nprof = min(args.steps, 20)
         prof = r.profile(nprof) if (not args.no_profile and rank == 0) else []
@@ -392,6 +411,7 @@ def main():
                        "memory_size": wl["M"], "frame": [wl["H"], wl["W"]], "frame_pipeline": mode_txt,
                        "precision": PRECISION_LABEL[os.environ.get("LBM_AMD_PRECISION", "split")], "parallelism": f"streams x{world} (no collective in the step)"},
             "p50_latency_ms": statistics.median(lat),
+            "p50_latency_graph_replay_ms": lat_graph,
             "step_algorithmic_TFLOPs": step_flops(wl, N, B) / (elapsed / args.steps) / 1e12,
         }
         per = lambda el: {"ms_per_step": 1e3 * el / args.steps, "value": total_pf / el, "unit": "point-frames/s"}

@@ -226,12 +226,12 @@ int stem_pool(const void* X, long long x_plane, const void* Wh, const void* Wl, 
   d.X = (const _Float16*)X; d.x_plane = x_plane; d.Wh = (const _Float16*)Wh; d.Wl = (const _Float16*)Wl; d.ldw = ldw; d.bias = bias;
   d.Y = Y; d.Ys = (_Float16*)Ys; d.ys_plane = ys_plane; d.B = B; d.H = H; d.W = W; d.Hp = H / 4; d.Wp = W / 4;
   d.strips = (d.Wp + 14) / 15;
-  // pooled rows per workgroup: short workgroups while they are few (one frame), up to 16 rows when there are thousands (each
+  // pooled rows per workgroup: short workgroups while they are few (one frame), up to 32 rows when there are thousands (each
   // workgroup recomputes one conv row of its upper neighbour and loads the weights once)
   const long long units = (long long)B * d.strips * d.Hp;
   long long rows = (units + 1023) / 1024;
   if (rows < 4) rows = 4;
-  if (rows > 16) rows = 16;
+  if (rows > 32) rows = 32;
   if (rows > d.Hp) rows = d.Hp;
   d.rows_per_wg = (int)rows;
   d.chunks = (d.Hp + d.rows_per_wg - 1) / d.rows_per_wg;

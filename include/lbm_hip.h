@@ -428,7 +428,9 @@ int lbm_hip_profile_end(lbm_hip_profile_entry* out, int32_t cap);
  *  15  many-rows fused feed-forward: 0 auto (above key 7's row count), 1 never, 2 always        16  its ablation bits
  *  17  offset and visibility heads as one batch of two (default 1)
  *  18  conv64_rows timing-only ablation bits (results are wrong when set): 1 no DMA after the prologue, 2 no epilogue,
- *      4 no first-half MFMAs, 8 no second-half MFMAs (default 0); convolution force mode (key 4) 15 = never, 16 = always      */
+ *      4 no first-half MFMAs, 8 no second-half MFMAs (default 0); convolution force mode (key 4) 15 = never, 16 = always
+ *  20  stem_pool timing-only ablation bits (results are wrong when set): 1 no DMA after the prologue, 2 no pooling / stores,
+ *      4 no MFMAs, 8 no hand-over writes (default 0)                                                                         */
 int lbm_hip_debug_set(int32_t key, int32_t value);
 /* the same for pointer-valued knobs: key 1 = device buffer (768 floats per 2x2 cell block) that correlation-map variant 2
  * (debug key 9 = 2) fills with what each wave loaded and computed -- reproduction aid; NULL = off */

@@ -35,7 +35,10 @@ struct StemDev {
   long long ys_plane;
   int B, H, W, Hp, Wp;
   int rows_per_wg, chunks, strips;
+  int dbg;   // tuning (timing only, debug key 20): 1 no DMA after the prologue, 2 no pooling / stores, 4 no MFMAs, 8 no hand-over writes
 };
+
+int g_stem_dbg = 0;
 
 typedef __attribute__((address_space(3))) void* lds_ptr_st;
 
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(512) void stem_pool_kernel(StemDev a) {
     const int fo = 16 * r + 16 * h;          // byte offset of this lane's fragment inside an input row (+ 32 for the second half of the taps)
     for (int t = 0; t <= n + 1; ++t) {
       handover();
-      if (t > n || (t == n && rp == 1)) continue;      // (conv row B of the last iteration belongs to the next workgroup)
+      if (t > n || (t == n && rp == 1) || (a.dbg & 4)) continue;      // (conv row B of the last iteration belongs to the next workgroup)
       const unsigned char* Pb = lds + (t & (NST - 1)) * PATCH + (2 * rp) * ROWB + fo;
       f32x16 acc, acx;
 #pragma unroll
@@ -126,8 +129,9 @@ __global__ __launch_bounds__(512) void stem_pool_kernel(StemDev a) {
         __builtin_amdgcn_sched_barrier(0);
       }
       float* Tw = reinterpret_cast<float*>(lds + OFF_FIN + (((t & 1) * 2 + rp) * 2 + cb) * FIN);
+      if (!(a.dbg & 8))
 #pragma unroll
-      for (int e = 0; e < 16; ++e) Tw[(4 * h + (e & 3) + 8 * (e >> 2)) * TP + r] = fmaxf((acc[e] + acx[e] * (1.0f / 2048.0f)) + bv, 0.f);
+        for (int e = 0; e < 16; ++e) Tw[(4 * h + (e & 3) + 8 * (e >> 2)) * TP + r] = fmaxf((acc[e] + acx[e] * (1.0f / 2048.0f)) + bv, 0.f);
     }
   } else if (role == 2) {
     // ---- DMA: iteration t needs input rows 4 (py0 + t) - 5 .. + 8, pixels 60 strip - 6 .. + 69 (two per lane, 35 lanes) ----
@@ -152,7 +156,7 @@ __global__ __launch_bounds__(512) void stem_pool_kernel(StemDev a) {
       if (t + 1 <= n) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");     // patch t landed, patch t + 1 may be in flight
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       handover();
-      if (t + 2 <= n) issue(t + 2);            // its stage held patch t - 2: last read in iteration t - 2
+      if (t + 2 <= n && !(a.dbg & 1)) issue(t + 2);            // its stage held patch t - 2: last read in iteration t - 2
     }
   } else {
     // ---- pooling.  Iteration t takes conv rows A = 2 (py0 + k) - 1 and B = 2 (py0 + k) of iteration k = t - 1: pooled row
@@ -169,7 +173,7 @@ __global__ __launch_bounds__(512) void stem_pool_kernel(StemDev a) {
     auto mx = [](const float4 p, const float4 q) { return make_float4(fmaxf(p.x, q.x), fmaxf(p.y, q.y), fmaxf(p.z, q.z), fmaxf(p.w, q.w)); };
     for (int t = 0; t <= n + 1; ++t) {
       handover();
-      if (t == 0) continue;
+      if (t == 0 || (a.dbg & 2)) continue;
       const int k = t - 1;
       const float* Ta = reinterpret_cast<const float*>(lds + OFF_FIN + (((k & 1) * 2 + 0) * 2 + cb) * FIN);
       const float* Tb = reinterpret_cast<const float*>(lds + OFF_FIN + (((k & 1) * 2 + 1) * 2 + cb) * FIN);
@@ -226,6 +230,7 @@ int stem_pool(const void* X, long long x_plane, const void* Wh, const void* Wl, 
   d.X = (const _Float16*)X; d.x_plane = x_plane; d.Wh = (const _Float16*)Wh; d.Wl = (const _Float16*)Wl; d.ldw = ldw; d.bias = bias;
   d.Y = Y; d.Ys = (_Float16*)Ys; d.ys_plane = ys_plane; d.B = B; d.H = H; d.W = W; d.Hp = H / 4; d.Wp = W / 4;
   d.strips = (d.Wp + 14) / 15;
+  d.dbg = g_stem_dbg;
   // pooled rows per workgroup: short workgroups while they are few (one frame), up to 32 rows when there are thousands (each
   // workgroup recomputes one conv row of its upper neighbour and loads the weights once)
   const long long units = (long long)B * d.strips * d.Hp;

@@ -115,3 +115,31 @@ def test_packed_weight_container_round_trip_and_rejections(tmp_path):
     d0 = packed.state_digest(sd)
     sd["y"][1] = float(np.nextafter(np.float32(1), np.float32(2)))
     assert packed.state_digest(sd) != d0 and len(d0) == 64
+
+
+def test_ctypes_mirrors_match_the_c_header(tmp_path):
+    """Every descriptor struct of include/lbm_hip.h against its ctypes mirror in lbm_amd/hip.py: same size, same field names, same
+    offsets -- checked by compiling a C program that prints offsetof() for the fields the Python side declares (gcc; no GPU)."""
+    import ctypes
+    import json
+    import subprocess
+    from lbm_amd import hip
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pairs = [("lbm_hip_linear_desc", hip.LinearDesc), ("lbm_hip_linear_ss_desc", hip.LinearSSDesc), ("lbm_hip_msda_desc", hip.MsdaDesc),
+             ("lbm_hip_step_desc", hip.StepDesc), ("lbm_hip_profile_entry", hip.ProfileEntry)]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "lbm_hip.h"', 'int main(void) {', '  printf("{");']
+    for cname, cls in pairs:
+        lines.append(f'  printf("\\"{cname}\\": {{\\"sizeof\\": %zu", sizeof({cname}));')
+        for fname, *_ in cls._fields_:
+            lines.append(f'  printf(", \\"{fname}\\": %zu", offsetof({cname}, {fname}));')
+        lines.append('  printf("}%s", "' + ("" if cname == pairs[-1][0] else ", ") + '");')
+    lines += ['  printf("}\\n");', '  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c11", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], check=True)
+    got = json.loads(subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout)
+    for cname, cls in pairs:
+        assert got[cname]["sizeof"] == ctypes.sizeof(cls), cname
+        for fname, *_ in cls._fields_:
+            assert got[cname][fname] == getattr(cls, fname).offset, f"{cname}.{fname}"

@@ -143,3 +143,24 @@ def test_ctypes_mirrors_match_the_c_header(tmp_path):
         assert got[cname]["sizeof"] == ctypes.sizeof(cls), cname
         for fname, *_ in cls._fields_:
             assert got[cname][fname] == getattr(cls, fname).offset, f"{cname}.{fname}"
+
+
+def test_ctypes_argument_lists_match_the_c_prototypes():
+    """Number of parameters of every prototype in include/lbm_hip.h against the argtypes lbm_amd/hip.py declares for it (a parameter
+    added on one side only would shift every later argument silently)."""
+    import re
+    from lbm_amd import hip
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "include", "lbm_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    lib = hip.load()
+    checked = 0
+    for m in re.finditer(r"\b(?:int|int64_t|uint64_t|const char\*)\s+(lbm_hip_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+        name, params = m.group(1), m.group(2).strip()
+        n = 0 if params in ("", "void") else params.count(",") + 1
+        fn = getattr(lib, name)
+        if fn.argtypes is None:
+            continue
+        assert len(fn.argtypes) == n, f"{name}: header has {n} parameters, hip.py declares {len(fn.argtypes)}"
+        checked += 1
+    assert checked >= 30

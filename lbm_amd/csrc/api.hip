@@ -162,6 +162,7 @@ static int g_ffn_sites = 63;        // tuning (debug key 8): 1 attention blocks,
 extern int g_ffn_rows_dbg;          // ffn.hip (debug key 16)
 extern int g_conv64_dbg;            // conv_rs.hip (debug key 18)
 extern int g_stem_dbg;              // stem_rs.hip (debug key 20)
+extern int g_msda_xcd;              // msda.hip (debug key 21)
 static int g_head_pair = 1;         // tuning (debug key 17): 0 = offset and visibility heads as two separate chains
 static int g_ffn_rows_mode = 0;     // tuning (debug key 15): 0 = many-rows fused feed-forward from g_ffn_fused_rows + 1 rows on, 1 = never, 2 = for any row count
 static int g_ffn_fused_rows = 2048; // tuning (debug key 7): most rows for which the feed-forward runs as one fused launch (0: never)
@@ -875,6 +876,10 @@ int lbm_hip_debug_set(int32_t key, int32_t value) {
   }
   if (key == 20) {
     lbm::g_stem_dbg = value;
+    return 0;
+  }
+  if (key == 21) {
+    lbm::g_msda_xcd = value;
     return 0;
   }
   if (key == 18) {

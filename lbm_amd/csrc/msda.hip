@@ -26,7 +26,21 @@ __global__ __launch_bounds__(256) void msda_sample_kernel(MsdaArgs a) {
   __shared__ float sm[LBM_HEADS][3][64];
   const int lane = threadIdx.x & 63;
   const int hd = threadIdx.x >> 6;
-  const long long rq = blockIdx.x;                                   // output row
+  // Row and reference cell of this workgroup.  Workgroups go to the 8 XCDs round-robin in dispatch order; with many streams
+  // (xcd_streams) the order is re-dealt so that XCD c works through streams c, c + 8, ... one at a time, the k cells of a point
+  // back to back: an L2 then holds the value map of ONE stream instead of a slice of eight (a bijection of the grid; B % 8 == 0).
+  long long rq = blockIdx.x;                                         // output row
+  int kk_ = blockIdx.y;
+  if (a.xcd_streams) {
+    const long long lin = (long long)blockIdx.y * gridDim.x + blockIdx.x;
+    const int c = (int)(lin & 7);
+    const long long t = lin >> 3;
+    const int per = a.N * a.k;                                       // workgroups of one stream
+    const long long j = t / per;
+    const int u = (int)(t - j * per);
+    rq = (j * 8 + c) * a.N + u / a.k;
+    kk_ = u % a.k;
+  }
   const int set = (a.set_rows != 0 && rq >= a.set_rows) ? 1 : 0;     // second module of a two-module launch (workgroup-uniform)
   const long long r = rq - (long long)set * a.set_rows;               // the point this row belongs to
   const int b = (int)(r / a.N);
@@ -65,7 +79,7 @@ __global__ __launch_bounds__(256) void msda_sample_kernel(MsdaArgs a) {
   const int tap = lane >> 4, tx = tap & 1, ty = tap >> 1, cq = lane & 15;
   const float* vb = a.value + (long long)b * a.v_batch_stride + set * a.set_value_off + hd * LBM_HD + cq * 4;
   {
-    const int kk = blockIdx.y;
+    const int kk = kk_;
     float rx = 0.f, ry = 0.f;
     if (!EXPLICIT) {
       const float* rp = a.ref + (r * a.k + kk) * 2;
@@ -110,6 +124,8 @@ __global__ __launch_bounds__(256) void msda_sample_kernel(MsdaArgs a) {
   }
 }
 
+int g_msda_xcd = 1;   // debug key 21: 0 = dispatch order
+
 int msda_sample(const MsdaArgs& a, hipStream_t stream) {
   const long long R = (long long)a.B * a.N;
   if (R == 0) return 0;
@@ -138,9 +154,11 @@ int msda_sample(const MsdaArgs& a, hipStream_t stream) {
     LBM_REQUIRE(a.k <= 65535, "msda_sample: k=%d too large", a.k);
     LBM_REQUIRE(a.set_rows == 0 || a.set_rows == R, "msda_sample: a two-module launch covers every point twice (set_rows == B * N)");
     const dim3 grid((unsigned)(a.set_rows ? 2 * R : R), (unsigned)a.k);
-    if (a.P == 9) hipLaunchKernelGGL((msda_sample_kernel<false, 9>), grid, dim3(256), 0, stream, a);
-    else if (a.P == 4) hipLaunchKernelGGL((msda_sample_kernel<false, 4>), grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((msda_sample_kernel<false, 0>), grid, dim3(256), 0, stream, a);
+    MsdaArgs b = a;
+    b.xcd_streams = (g_msda_xcd && a.set_rows == 0 && a.B >= 8 && a.B % 8 == 0) ? 1 : 0;
+    if (a.P == 9) hipLaunchKernelGGL((msda_sample_kernel<false, 9>), grid, dim3(256), 0, stream, b);
+    else if (a.P == 4) hipLaunchKernelGGL((msda_sample_kernel<false, 4>), grid, dim3(256), 0, stream, b);
+    else hipLaunchKernelGGL((msda_sample_kernel<false, 0>), grid, dim3(256), 0, stream, b);
   }
   return check_launch("msda_sample");
 }

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void msda_sample_kernel(MsdaArgs a) {
     const int per = a.N * a.k;                                       // workgroups of one stream
     const long long j = t / per;
     const int u = (int)(t - j * per);
-    rq = (j * 8 + c) * a.N + u / a.k;
+    rq = (j * 8 + c) * a.N + u / a.k;          // (two-module launches: unit j * 8 + c runs over (module, stream) -- rows [R, 2R) follow [0, R))
     kk_ = u % a.k;
   }
   const int set = (a.set_rows != 0 && rq >= a.set_rows) ? 1 : 0;     // second module of a two-module launch (workgroup-uniform)
@@ -155,7 +155,7 @@ int msda_sample(const MsdaArgs& a, hipStream_t stream) {
     LBM_REQUIRE(a.set_rows == 0 || a.set_rows == R, "msda_sample: a two-module launch covers every point twice (set_rows == B * N)");
     const dim3 grid((unsigned)(a.set_rows ? 2 * R : R), (unsigned)a.k);
     MsdaArgs b = a;
-    b.xcd_streams = (g_msda_xcd && a.set_rows == 0 && a.B >= 8 && a.B % 8 == 0) ? 1 : 0;
+    b.xcd_streams = (g_msda_xcd && a.B >= 8 && a.B % 8 == 0) ? 1 : 0;
     if (a.P == 9) hipLaunchKernelGGL((msda_sample_kernel<false, 9>), grid, dim3(256), 0, stream, b);
     else if (a.P == 4) hipLaunchKernelGGL((msda_sample_kernel<false, 4>), grid, dim3(256), 0, stream, b);
     else hipLaunchKernelGGL((msda_sample_kernel<false, 0>), grid, dim3(256), 0, stream, b);

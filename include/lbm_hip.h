@@ -430,7 +430,9 @@ int lbm_hip_profile_end(lbm_hip_profile_entry* out, int32_t cap);
  *  18  conv64_rows timing-only ablation bits (results are wrong when set): 1 no DMA after the prologue, 2 no epilogue,
  *      4 no first-half MFMAs, 8 no second-half MFMAs (default 0); convolution force mode (key 4) 15 = never, 16 = always
  *  20  stem_pool timing-only ablation bits (results are wrong when set): 1 no DMA after the prologue, 2 no pooling / stores,
- *      4 no MFMAs, 8 no hand-over writes (default 0)                                                                         */
+ *      4 no MFMAs, 8 no hand-over writes (default 0)
+ *  21  msda_sample with a batch of streams: 1 (default) workgroups dealt so that each XCD works through one stream's value map
+ *      at a time, 0 dispatch order                                                                                            */
 int lbm_hip_debug_set(int32_t key, int32_t value);
 /* the same for pointer-valued knobs: key 1 = device buffer (768 floats per 2x2 cell block) that correlation-map variant 2
  * (debug key 9 = 2) fills with what each wave loaded and computed -- reproduction aid; NULL = off */

@@ -263,3 +263,25 @@ def test_encoder_tail_row_norms_are_the_norm_kernels(hip):
     assert torch.equal(inv.view(torch.int32), inv2.view(torch.int32))
     want = 1.0 / tok.double().norm(dim=-1).clamp_min(1e-12)
     assert float(((inv.double() - want) / want).abs().max()) < 1e-6
+
+
+@pytest.mark.parametrize("B,N,k,P", [(8, 5, 3, 9), (16, 33, 9, 9), (8, 7, 1, 4), (24, 3, 4, 9)])
+def test_msda_xcd_aware_order_gives_the_same_rows(hip, B, N, k, P):
+    """msda_sample with a batch of streams re-deals its workgroups over the XCDs (debug key 21): a bijection of the grid, so every
+    output row must equal the dispatch-order run bit for bit -- stream counts 8, 16, 24, odd point counts, k = 1, 3, 4, 9."""
+    lib = hip.load()
+    g = torch.Generator(device="cpu").manual_seed(B * 100 + N * 10 + k)
+    shapes = [(16, 24), (8, 12), (4, 6), (2, 3)]
+    L = sum(h * w for h, w in shapes)
+    value = torch.randn(B, L, 256, generator=g).cuda()
+    offlog = (torch.randn(B * N, 48 * P, generator=g) * 2.0).cuda()
+    ref = (torch.rand(B * N, k, 2, generator=g) * torch.tensor([96.0, 64.0])).cuda()
+    outs = []
+    try:
+        for mode in (0, 1):
+            lib.lbm_hip_debug_set(21, mode)
+            outs.append(hip.msda_sample(value, shapes, offlog, ref, B, N, k, P, 96.0, 64.0))
+    finally:
+        lib.lbm_hip_debug_set(21, 1)
+    assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))
+    assert bool(torch.isfinite(outs[1]).all()) and float(outs[1].abs().max()) > 0

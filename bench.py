@@ -9,11 +9,15 @@ for every stream the rank owns; frames are resident in HBM before the timed regi
   c2 (default at N = 1, the configuration the metric is quoted on):  1 stream, 480x854, dense 32x32 grid = 1024 points, M = 12
   c3 (default at N > 1: BASELINE config 4 = 64 streams per GPU):     64 streams x 256 points, 480x854, batched in one step
   c5:  1 stream, 1080x1920, dense 100x100 grid = 10 000 points, memory M = 48
+  c1:  1 stream, 480x854, 8 fixed "clicked" points (BASELINE config 1, the reference's own CPU-runnable case; demo_click.py:40-48):
+       reported under ``workloads.c1`` as the CPU oracle's ms/frame and the GPU's p50 latency, eager and graph-replayed, plus the
+       10-point figure the reference publishes its own numbers at (assets/tensorrt.md:106-107)
 
 Two frame loops are timed on the same K frames from the same state: strictly serial frames, and the frame pipeline
 (LBM_online.prefetch: encoder of frame t+1 on a second HIP stream).  ``value`` is the pipelined figure only when its final
-tracks, logits and memories are bit-identical to the serial loop's in this very run (``pipeline_bit_identical``, DESIGN.md
-section 8) and it is faster; otherwise the serial figure.  Both are in the line (``serial_frames``, ``frame_pipeline``).
+tracks and logits of EVERY timed frame (a whole-run log the step writes into, no extra launches) and its final memories are
+bit-identical to the serial loop's in this very run (``pipeline_bit_identical``, DESIGN.md section 8) and it is faster;
+otherwise the serial figure.  Both are in the line (``serial_frames``, ``frame_pipeline``).
 At N = 1 the line also carries ``workloads``: the throughput regime (c3, c5) measured in the same process.
 
 N > 1: ``python bench.py --gpus N`` starts N ranks itself (child ``torch.distributed.run`` before anything touches the
@@ -38,6 +42,8 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 WORKLOADS = {
+    "c1": dict(desc="1 stream 480x854, 8 fixed clicked points, memory 12", B=1, clicks=8, H=480, W=854, M=12, frames=8),
+    "c1_10": dict(desc="1 stream 480x854, 10 fixed clicked points, memory 12", B=1, clicks=10, H=480, W=854, M=12, frames=8),
     "c2": dict(desc="1 stream 480x854, dense 32x32 grid (1024 points), memory 12", B=1, grid=32, H=480, W=854, M=12, frames=8),
     "c3": dict(desc="64 streams 480x854 x 256 random points, memory 12", B=64, npts=256, H=480, W=854, M=12, frames=2),
     "c5": dict(desc="1 stream 1080x1920, dense 100x100 grid (10000 points), memory 48", B=1, grid=100, H=1080, W=1920, M=48, frames=4),
@@ -70,6 +76,15 @@ def build_model(wl, device):
     return model, sd
 
 
+def clicked_points(n, H, W, seed=42):
+    """BASELINE config 1's "clicked" query points: a GUI click is impossible headless (demo_utils.py:73-93), so n fixed seeded
+    points, uniform in the central 80 % of the frame, integer pixels like a click."""
+    import numpy as np
+    g = np.random.Generator(np.random.PCG64(seed * 7919 + n))
+    xy = np.rint(g.uniform([0.1 * W, 0.1 * H], [0.9 * W, 0.9 * H], (n, 2))).astype("float32")
+    return torch.from_numpy(xy)
+
+
 def make_inputs(wl, rank):
     from lbm_amd.synth import synthetic_video, grid_queries, random_queries
     H, W, B = wl["H"], wl["W"], wl["B"]
@@ -78,7 +93,8 @@ def make_inputs(wl, rank):
     for s in range(B):
         # streams of a batch: the same clip shifted by s pixels (cheap to generate, different content per stream)
         vids.append(torch.roll(base, shifts=(3 * s) % W, dims=-1) if s else base)
-        pts.append(grid_queries(H, W, wl["grid"]) if "grid" in wl else random_queries(wl["npts"], H, W, 42 + rank * 1000 + s))
+        pts.append(clicked_points(wl["clicks"], H, W) if "clicks" in wl else grid_queries(H, W, wl["grid"]) if "grid" in wl else
+                   random_queries(wl["npts"], H, W, 42 + rank * 1000 + s))
     video = torch.stack(vids, 0)                                                 # (B,T,3,H,W)
     return video, torch.stack(pts, 0)                                            # (B,N,2)
 
@@ -163,18 +179,27 @@ class Runner:
         self.frames = [video[:, 1 + i].contiguous() for i in range(self.nfr)]
         self.tok = None
 
-    def run(self, n, pipeline=False, first=0):
+    def new_log(self, n):
+        """Result tensors of n frames, which the step writes in place (LBM_online.online_forward_batch(out=...)): the tracks and
+        logits of EVERY timed frame are kept and compared between the two frame loops at no cost inside the timed region."""
+        dev, B, N = self.pts.device, self.B, self.N
+        f = lambda *sh: torch.zeros(n, B, N, *sh, device=dev)
+        return {"coords": f(2), "vis": f(), "rho": f(), "offset": f(2), "rho_prob": f(),
+                "vis_flag": torch.zeros(n, B, N, device=dev, dtype=torch.bool)}
+
+    def run(self, n, pipeline=False, first=0, log=None):
         """n complete frames (n encoder passes, n tracker passes).  Pipelined, the encoder of frame i+1 is enqueued on a second
         HIP stream before the per-point phase of frame i (the first frame is encoded inline, the last prefetches nothing)."""
         m, fr, nfr = self.model, self.frames, self.nfr
         out = None
         for i in range(first, first + n):
+            dst = None if log is None else {k: v[i - first] for k, v in log.items()}
             if pipeline:
                 if i + 1 < first + n:
                     m.prefetch(fr[(i + 1) % nfr])
-                out = m.online_forward_batch(fr[i % nfr])
+                out = m.online_forward_batch(fr[i % nfr], out=dst)
             else:
-                out = m.online_forward_batch(fr[i % nfr], tokens=self.tok)
+                out = m.online_forward_batch(fr[i % nfr], tokens=self.tok, out=dst)
                 self.tok = out[3]
         if pipeline:
             self.tok = None
@@ -189,11 +214,61 @@ class Runner:
         m._stream.copy_(snap[0]); m._coll.copy_(snap[1]); m._vis.copy_(snap[2]); m._mem.copy_(snap[3])
         m._head, m.t = snap[4], snap[5]
 
-    def fingerprint(self, out):
-        """Everything a frame loop leaves behind: the last frame's tracks and logits, and both memories with their masks."""
+    def fingerprint(self, log):
+        """Everything a frame loop leaves behind: the tracks, logits and flags of every frame, and both memories with their masks."""
         m = self.model
-        return [out[0].clone(), m.last_logits[0].clone(), m.last_logits[1].clone(), out[1].clone(), m._stream.clone(), m._coll.clone(),
-                m._vis.clone(), m._mem.clone()]
+        return [log[k] for k in sorted(log)] + [m._stream.clone(), m._coll.clone(), m._vis.clone(), m._mem.clone()]
+
+    def time_loops(self, steps, warmup, barrier, want_pipeline=True):
+        """Both frame loops on the same `steps` frames from the same state, each bracketed by `barrier` (synchronize, and the
+        process-group barrier at N > 1).  -> (seconds serial, seconds pipelined or None, bit-identical?, last frame's outputs)."""
+        self.run(warmup)
+        torch.cuda.synchronize()
+        snap = self.snapshot()
+        log_s = self.new_log(steps)
+        barrier()
+        t0 = time.perf_counter()
+        out = self.run(steps, log=log_s)
+        barrier()
+        el_serial = time.perf_counter() - t0
+        fp_serial = self.fingerprint(log_s)
+        el_pipe, same = None, False
+        if want_pipeline:
+            self.restore(snap)
+            self.run(2, pipeline=True)                            # (its first use allocates the second slot)
+            self.restore(snap)
+            log_p = self.new_log(steps)
+            barrier()
+            t1 = time.perf_counter()
+            self.run(steps, pipeline=True, log=log_p)
+            barrier()
+            el_pipe = time.perf_counter() - t1
+            same = all(torch.equal(a, b) for a, b in zip(fp_serial, self.fingerprint(log_p)))
+        return el_serial, el_pipe, same, (out[0], out[1], out[2])
+
+    def p50(self, n, graph=False):
+        """Median per-frame latency, every (serial) frame synchronised on its own; graph=True: the frame step replayed as a HIP
+        graph (LBM_online.use_graph, one graph per ring position).  None if the capture was not possible."""
+        m = self.model
+        if graph and getattr(m, "use_graph", None) is None:
+            return None
+        try:
+            if graph:
+                m.use_graph = True
+                self.run(self.wl["M"] + 2)                    # first use of a ring position captures its graph
+            lat = []
+            for i in range(n):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                self.run(1, first=i)
+                torch.cuda.synchronize()
+                lat.append((time.perf_counter() - t1) * 1e3)
+            if graph and not m.use_graph:                     # (a failed capture switches the model back to eager launches)
+                return None
+            return statistics.median(lat)
+        finally:
+            if graph:
+                m.use_graph = False
 
     def profile(self, nprof):
         from lbm_amd import hip
@@ -205,6 +280,80 @@ class Runner:
             p["avg_us"] = 1e3 * p["total_ms"] / max(p["launches"], 1)
             p["per_step_us"] = 1e3 * p["total_ms"] / nprof
         return prof
+
+
+def attach_traffic(roof, prof, wname):
+    """(prof may be None: then only the counter figure is attached)"""
+    return _attach_traffic(roof, prof, wname)
+
+
+def _attach_traffic(roof, prof, wname):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate
+    runs, gfx950 corrections applied by scripts/pmc_traffic.py); counters cannot be read from inside this process."""
+    pmc = sorted((pathlib.Path(__file__).parent / "profiles").glob(f"r*_{wname}_pmc.json"))
+    if not pmc:
+        return
+    ent = json.loads(pmc[-1].read_text())["kernels"].get(roof["kernel"])
+    if ent:
+        roof["traffic"] = ent["traffic_bytes_per_launch"]
+        roof["traffic_source"] = f"profiles/{pmc[-1].name}"
+        dom = next((p for p in (prof or []) if p["name"] == roof["kernel"]), None)
+        if dom is not None:
+            roof["algorithmic_bytes_per_launch"] = dom["bytes"] / max(dom["launches"], 1)
+
+
+def measure_throughput(name, steps, warmup, rank, device, sync, profile=True, precision=None):
+    """One entry of `workloads`: the same Runner.time_loops as the headline (so `--workload c3` and `workloads.c3` are the same
+    measurement up to the step count), plus the roofline entry of its dominant kernel."""
+    w2 = WORKLOADS[name]
+    old = os.environ.get("LBM_AMD_PRECISION")
+    if precision is not None:
+        os.environ["LBM_AMD_PRECISION"] = precision
+    try:
+        r2 = Runner(w2, rank, device)
+        e_s, e_p, same2, _ = r2.time_loops(steps, warmup, sync)
+        prof2 = r2.profile(4) if profile else []
+        roof2, kern2 = roofline_of(prof2, 4)
+        if roof2 is not None and precision is None:
+            attach_traffic(roof2, prof2, name)
+    finally:
+        if precision is not None:
+            if old is None:
+                os.environ.pop("LBM_AMD_PRECISION", None)
+            else:
+                os.environ["LBM_AMD_PRECISION"] = old
+    fl = step_flops(w2, r2.N, r2.B)
+    ent = {"workload": w2["desc"], "steps": steps, "ms_per_step": 1e3 * e_s / steps,
+           "value": float(r2.B) * r2.N * steps / e_s, "unit": "point-frames/s",
+           "dtype": "f16" if precision in ("f16", "f16s") else "f32",
+           "step_algorithmic_TFLOPs": fl / (e_s / steps) / 1e12,
+           "step_frac_of_f16_mfma_peak": fl / (e_s / steps) / 1e12 / F16_MFMA_PEAK_TF,
+           "frame_pipeline": {"ms_per_step": 1e3 * e_p / steps, "value": float(r2.B) * r2.N * steps / e_p, "bit_identical": same2},
+           "roofline": roof2, "kernels": kern2[:6]}
+    if precision is not None:
+        ent["precision"] = PRECISION_LABEL[precision]
+    del r2
+    torch.cuda.empty_cache()
+    return ent
+
+
+def measure_clicks(name, rank, device, cpu=False):
+    """BASELINE config 1 (8 clicked points, one 480x854 stream; the 10-point variant is what assets/tensorrt.md:104-109 quotes):
+    a latency regime -- p50 of single synchronised frames, eager and graph-replayed -- and, for c1 itself, the CPU oracle."""
+    w = WORKLOADS[name]
+    r = Runner(w, rank, device)
+    r.run(10)                                         # warm-up as benchmark_torch.py:61-62
+    lat = r.p50(50)
+    lat_g = r.p50(50, graph=True)
+    ent = {"workload": w["desc"], "p50_latency_ms": lat, "p50_latency_graph_replay_ms": lat_g, "frames_timed": 50, "dtype": "f32",
+           "value": r.N / (min(x for x in (lat, lat_g) if x is not None) / 1e3), "unit": "point-frames/s"}
+    if name == "c1_10":
+        ent["reference_published"] = "assets/tensorrt.md:106-107: 20.50 ms PyTorch / 3.84 ms TensorRT-FP16 at 10 points on an RTX 4090 (other hardware, real weights)"
+    if cpu:
+        ent["cpu_baseline"] = cpu_baseline(w, r.sd, r.video_cpu, r.pts_cpu, budget_s=6.0)
+    del r
+    torch.cuda.empty_cache()
+    return ent
 
 
 def spawn_ranks(args):
@@ -237,6 +386,8 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--allow-knobs", action="store_true", help="tuning run with lbm_hip_debug_set knobs off their defaults (LBM_DEBUG_SET) "
+                    "or a -DLBM_TUNING library: the line carries headline_valid = false")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -264,7 +415,15 @@ def main():
     from lbm_amd import hip
     for kv in os.environ.get("LBM_DEBUG_SET", "").split(","):        # tuning knobs, e.g. LBM_DEBUG_SET=3:4
         if kv:
-            hip.load().lbm_hip_debug_set(int(kv.split(":")[0]), int(kv.split(":")[1]))
+            hip._check(hip.load().lbm_hip_debug_set(int(kv.split(":")[0]), int(kv.split(":")[1])), "LBM_DEBUG_SET")
+    # A figure measured with a knob off its default is a tuning experiment, not a headline: the knobs are printed in the line
+    # (`config.knobs`) and the run is refused unless --allow-knobs says it is meant (then `headline_valid` is false).
+    knobs = hip.debug_active()
+    env_knobs = {k: os.environ[k] for k in sorted(os.environ) if k.startswith("LBM_AMD_") and k not in ("LBM_AMD_LIB",)}
+    tuning_lib = bool(hip.load().lbm_hip_tuning_build())
+    if (knobs or tuning_lib) and not args.allow_knobs:
+        raise SystemExit(f"bench.py: debug knobs {knobs} are set / tuning build = {tuning_lib}; a headline needs the product library at its "
+                         f"defaults (pass --allow-knobs for a tuning run: the line then says headline_valid = false)")
 
     def barrier():
         torch.cuda.synchronize()
@@ -272,145 +431,87 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def local_sync():
+        torch.cuda.synchronize()
+
     # Both frame loops are timed on the same K frames from the same starting state, each bracketed by barrier + synchronize.
-    # The headline is the frame pipeline ONLY IF its final tracks, logits and memories are bit-identical to the serial run's on
-    # every rank (pipeline_bit_identical); otherwise -- or with --no-pipeline -- it is the serial figure.  --pipeline forces
-    # nothing past that check either.
+    # The headline is the frame pipeline ONLY IF the tracks, logits and flags of every timed frame and the final memories are
+    # bit-identical to the serial run's on every rank (pipeline_bit_identical); otherwise -- or with --no-pipeline -- it is the
+    # serial figure.
     want_pipeline = not args.no_pipeline and os.environ.get("LBM_AMD_PIPELINE") != "0"
+    from lbm_amd.sharding import gather_tracks, max_over_ranks, pack_tracks
+    cdev = device if args.backend == "nccl" else torch.device("cpu")
     with torch.no_grad():
         r = Runner(wl, rank, device)
         B, N = r.B, r.N
-        r.run(args.warmup)
-        torch.cuda.synchronize()
-        snap = r.snapshot()
-        barrier()
-        t0 = time.perf_counter()
-        out = r.run(args.steps)
-        barrier()
-        el_serial = time.perf_counter() - t0
-        coords, vis, rho = out[0], out[1], out[2]
-        fp_serial = r.fingerprint(out)
-        el_pipe, same = None, False
-        if want_pipeline:
-            r.restore(snap)
-            r.run(2, pipeline=True)                            # (its first use allocates the second slot)
-            r.restore(snap)
-            barrier()
-            t1 = time.perf_counter()
-            out2 = r.run(args.steps, pipeline=True)
-            barrier()
-            el_pipe = time.perf_counter() - t1
-            same = all(torch.equal(a, b) for a, b in zip(fp_serial, r.fingerprint(out2)))
-            del out2
+        el_serial, el_pipe, same, (coords, vis, rho) = r.time_loops(args.steps, args.warmup, barrier, want_pipeline)
+        my_serial, my_pipe = el_serial, el_pipe
         if dist is not None and want_pipeline:                 # one verdict for the whole job: identical on EVERY rank
-            flag = torch.tensor([1 if same else 0], device=device if args.backend == "nccl" else "cpu")
+            flag = torch.tensor([1 if same else 0], device=cdev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             same = bool(flag.item())
-        del fp_serial
 
-        # p50 per-frame latency: each (serial) frame synchronised on its own
-        lat = []
-        for i in range(min(args.steps, 50)):
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            r.run(1, first=i)
-            torch.cuda.synchronize()
-            lat.append((time.perf_counter() - t1) * 1e3)
+        # results travel over RCCL only here (gather of the last frame's tracks), as the north star asks -- straight after the
+        # timed loops on every rank, nothing (no latency or profiling pass) in between
+        res = pack_tracks(coords, vis, rho)                                                          # (B, N, 4) records
+        if args.backend == "gloo":
+            res = res.cpu()
+        gathered = gather_tracks(res, B * world, dst=0)
+        if rank == 0:
+            assert gathered.shape == (B * world, N, 4) and bool(torch.isfinite(gathered).all())
+        el_serial = max_over_ranks(el_serial, cdev)
+        if el_pipe is not None:
+            el_pipe = max_over_ranks(el_pipe, cdev)
+        ranks = None
+        if dist is not None:
+            mine = {"rank": rank, "device": torch.cuda.get_device_name(device), "device_index": local,
+                    "serial_ms_per_step": 1e3 * my_serial / args.steps,
+                    "pipelined_ms_per_step": None if my_pipe is None else 1e3 * my_pipe / args.steps}
+            ranks = [None] * world
+            dist.all_gather_object(ranks, mine)
 
-        # the same with the frame step replayed as a HIP graph (LBM_online.use_graph, one graph per ring position): what a
-        # latency-bound caller would run; reported beside the eager figure, never instead of it
-        lat_graph = None
-        if world == 1 and getattr(r.model, "use_graph", None) is not None and not args.no_profile:
-            try:
-                r.model.use_graph = True
-                r.run(wl["M"] + 2)                    # first use of a ring position captures its graph
-                lg = []
-                for i in range(min(args.steps, 50)):
-                    torch.cuda.synchronize()
-                    t1 = time.perf_counter()
-                    r.run(1, first=i)
-                    torch.cuda.synchronize()
-                    lg.append((time.perf_counter() - t1) * 1e3)
-                if r.model.use_graph:                  # (a failed capture switches the model back to eager launches)
-                    lat_graph = statistics.median(lg)
-            finally:
-                r.model.use_graph = False
-
-        # per-kernel HIP-event timing of the same step (separate pass so the events do not perturb `elapsed`)
+        lat = lat_graph = None
+        prof, extra = [], {}
         nprof = min(args.steps, 20)
-        prof = r.profile(nprof) if (not args.no_profile and rank == 0) else []
+        if world == 1:
+            # p50 per-frame latency: each (serial) frame synchronised on its own; and the same with the frame step replayed as a
+            # HIP graph: what a latency-bound caller would run; reported beside the eager figure, never instead of it
+            lat = r.p50(min(args.steps, 50))
+            if not args.no_profile:
+                lat_graph = r.p50(min(args.steps, 50), graph=True)
+                # per-kernel HIP-event timing of the same step (separate pass so the events do not perturb `elapsed`)
+                prof = r.profile(nprof)
+        sd, video_cpu, pts_cpu = r.sd, r.video_cpu, r.pts_cpu
 
-        # N = 1: the throughput regime in the same line (BASELINE configs 3 and 5), fewer steps each
-        extra = {}
+        # N = 1: the throughput regime (BASELINE configs 3 and 5) and the click regime (config 1) in the same line
         if world == 1 and not args.no_extra_workloads and args.workload is None:
-            sd_keep, vid_keep, pts_keep = r.sd, r.video_cpu, r.pts_cpu
-            del r, out, snap
+            del r
             torch.cuda.empty_cache()
             for name, steps in (("c3", 12), ("c5", 30)):
-                w2 = WORKLOADS[name]
-                r2 = Runner(w2, rank, device)
-                r2.run(4)
-                torch.cuda.synchronize()
-                snap2 = r2.snapshot()
-                t1 = time.perf_counter()
-                o_s = r2.run(steps)
-                torch.cuda.synchronize()
-                e_s = time.perf_counter() - t1
-                f_s = r2.fingerprint(o_s)
-                r2.restore(snap2)
-                r2.run(2, pipeline=True)
-                r2.restore(snap2)
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                o_p = r2.run(steps, pipeline=True)
-                torch.cuda.synchronize()
-                e_p = time.perf_counter() - t1
-                same2 = all(torch.equal(a, b) for a, b in zip(f_s, r2.fingerprint(o_p)))
-                roof2, _ = roofline_of(r2.profile(4), 4) if not args.no_profile else (None, [])
-                fl = step_flops(w2, r2.N, r2.B)
-                extra[name] = {"workload": w2["desc"], "steps": steps, "ms_per_step": 1e3 * e_s / steps,
-                               "value": float(r2.B) * r2.N * steps / e_s, "unit": "point-frames/s",
-                               "step_algorithmic_TFLOPs": fl / (e_s / steps) / 1e12,
-                               "step_frac_of_f16_mfma_peak": fl / (e_s / steps) / 1e12 / F16_MFMA_PEAK_TF,
-                               "frame_pipeline": {"ms_per_step": 1e3 * e_p / steps, "value": float(r2.B) * r2.N * steps / e_p,
-                                                  "bit_identical": same2},
-                               "roofline": roof2}
-                del r2, o_s, o_p, f_s, snap2
-                torch.cuda.empty_cache()
-            sd, video_cpu, pts_cpu = sd_keep, vid_keep, pts_keep
-        else:
-            sd, video_cpu, pts_cpu = r.sd, r.video_cpu, r.pts_cpu
-
-    # results travel over RCCL only here (gather of the last frame's tracks), as the north star asks
-    from lbm_amd.sharding import gather_tracks, max_over_ranks, pack_tracks
-    res = pack_tracks(coords, vis, rho)                                                          # (B, N, 4) records
-    if args.backend == "gloo":
-        res = res.cpu()
-    gathered = gather_tracks(res, B * world, dst=0)
-    if rank == 0:
-        assert gathered.shape == (B * world, N, 4) and bool(torch.isfinite(gathered).all())
-    cdev = device if args.backend == "nccl" else torch.device("cpu")
-    el_serial = max_over_ranks(el_serial, cdev)
-    if el_pipe is not None:
-        el_pipe = max_over_ranks(el_pipe, cdev)
+                extra[name] = measure_throughput(name, steps, 4, rank, device, local_sync, not args.no_profile)
+            for name in ("c1", "c1_10"):
+                extra[name] = measure_clicks(name, rank, device, cpu=(name == "c1" and not args.no_cpu_baseline))
     headline_pipelined = el_pipe is not None and same and el_pipe < el_serial
     elapsed = el_pipe if headline_pipelined else el_serial
 
     if rank == 0:
         total_pf = float(B) * N * world * args.steps
         mode_txt = ("encoder + value/correlation maps of frame t+1 on a second HIP stream, overlapping the per-point phase of frame t; "
-                    "verified bit-identical to the serial frame loop on these frames in this run" if headline_pipelined else
+                    "every timed frame verified bit-identical to the serial frame loop in this run" if headline_pipelined else
                     "none in the headline (strictly serial frames)" + ("" if el_pipe is None else
                                                                       ": the pipelined loop was " + ("not bit-identical" if not same else "not faster")))
+        prec = os.environ.get("LBM_AMD_PRECISION", "split")
         line = {
             "metric": "point-frames/sec (whole node) dense-grid tracking; p50 per-frame latency",
             "value": total_pf / elapsed, "unit": "point-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16" if os.environ.get("LBM_AMD_PRECISION", "split") == "f16" else "f32", "data": "synthetic (seeded video, seeded lbm.pt-layout weights)",
+            "dtype": "f16" if prec in ("f16", "f16s") else "f32", "data": "synthetic (seeded video, seeded lbm.pt-layout weights)",
             "config": {"workload": f"{wname}: {wl['desc']}", "streams_per_gpu": B, "points_per_stream": N,
                        "memory_size": wl["M"], "frame": [wl["H"], wl["W"]], "frame_pipeline": mode_txt,
-                       "precision": PRECISION_LABEL[os.environ.get("LBM_AMD_PRECISION", "split")], "parallelism": f"streams x{world} (no collective in the step)"},
-            "p50_latency_ms": statistics.median(lat),
+                       "precision": PRECISION_LABEL[prec], "parallelism": f"streams x{world} (no collective in the step)",
+                       "knobs": {"debug_set": {str(k): v for k, v in knobs.items()}, "env": env_knobs, "tuning_build": tuning_lib}},
+            "headline_valid": not knobs and not tuning_lib,
+            "p50_latency_ms": lat,
             "p50_latency_graph_replay_ms": lat_graph,
             "step_algorithmic_TFLOPs": step_flops(wl, N, B) / (elapsed / args.steps) / 1e12,
         }
@@ -419,19 +520,21 @@ def main():
         if el_pipe is not None:
             line["frame_pipeline"] = per(el_pipe)
             line["pipeline_bit_identical"] = same
+            line["pipeline_compared"] = f"coords, offsets, vis / rho logits, flags and probabilities of all {args.steps} timed frames + both memories and masks"
         line["headline_mode"] = "frame_pipeline" if headline_pipelined else "serial_frames"
+        if world > 1:
+            line["backend"] = dist.get_backend()
+            line["world_size"] = dist.get_world_size()
+            line["ranks"] = ranks
+            line["gathered_records"] = list(gathered.shape)
+        # a scaling curve needs real GPUs behind every rank: a single-device / gloo rehearsal is not one
+        line["scaling_measured"] = bool(world > 1 and args.backend == "nccl" and not args.single_device)
+        if not line["scaling_measured"]:
+            line["scaling_note"] = ("no 1/2/4/8-GPU curve has been measured on hardware in this repository yet (the driver had no 8-GPU node in "
+                                    "rounds 1-2); a run with --gpus N > 1 over RCCL is one point of it")
         roof, kernels = roofline_of(prof, nprof)
         if roof is not None:
-            # HBM-side bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate
-            # runs, gfx950 corrections applied by scripts/pmc_traffic.py); counters cannot be read from inside this process
-            pmc = sorted((pathlib.Path(__file__).parent / "profiles").glob(f"r*_{wname}_pmc.json"))
-            if pmc:
-                ent = json.loads(pmc[-1].read_text())["kernels"].get(roof["kernel"])
-                if ent:
-                    dom = next(p for p in prof if p["name"] == roof["kernel"])
-                    roof["traffic"] = ent["traffic_bytes_per_launch"]
-                    roof["traffic_source"] = f"profiles/{pmc[-1].name}"
-                    roof["algorithmic_bytes_per_launch"] = dom["bytes"] / max(dom["launches"], 1)
+            attach_traffic(roof, prof, wname)
             line["roofline"] = roof
             line["kernels"] = kernels
         if extra:

@@ -416,7 +416,9 @@ int lbm_hip_profile_begin(void);
 int lbm_hip_profile_end(lbm_hip_profile_entry* out, int32_t cap);
 
 /* tuning / debugging knobs (process-wide; 0 restores the default unless noted).  None changes results beyond the last bit except
- * the reproducer variants of key 9 and the ablation bits of keys 14 / 16 (timing only).
+ * the reproducer variants of key 9 and the timing-only ablation switches (keys 14 / 16 / 18 bits 0-7 / 20 and bits 12.. of key 2:
+ * results are WRONG when set).  The ablation code exists only in the tuning build (`make -C lbm_amd/csrc tuning`, -DLBM_TUNING ->
+ * liblbm_hip_tuning.so, see lbm_hip_tuning_build): the product library refuses those values with an error.
  *   1  force the split-GEMM tiling (1..23, gemm16.hip)          2  split-GEMM flags (256 = never / 512 = always the row-streaming
  *   3  attention read-out mode                                      kernel, 32 = no XCD remap, bits 12.. = its ablation switches)
  *   4  force the convolution tiling (1..14)                     5  dense top-k mode
@@ -434,6 +436,11 @@ int lbm_hip_profile_end(lbm_hip_profile_entry* out, int32_t cap);
  *  21  msda_sample with a batch of streams: 1 (default) workgroups dealt so that each XCD works through one stream's value map
  *      at a time, 0 dispatch order                                                                                            */
 int lbm_hip_debug_set(int32_t key, int32_t value);
+/* The knobs that currently differ from their defaults (what a measurement must state beside its figure; bench.py prints them
+ * in `config.knobs` and refuses a headline when any is set): writes up to `cap` (key, value) pairs, returns how many there are. */
+int32_t lbm_hip_debug_active(int32_t* keys, int32_t* values, int32_t cap);
+/* 1 when the library was compiled with -DLBM_TUNING (timing-only ablation code present), 0 for the product build */
+int32_t lbm_hip_tuning_build(void);
 /* the same for pointer-valued knobs: key 1 = device buffer (768 floats per 2x2 cell block) that correlation-map variant 2
  * (debug key 9 = 2) fills with what each wave loaded and computed -- reproduction aid; NULL = off */
 int lbm_hip_debug_ptr(int32_t key, void* p);

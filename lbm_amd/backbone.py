@@ -63,6 +63,9 @@ class Backbone(nn.Module):
         nn.init.trunc_normal_(self.frame_pos_embedding, std=0.02)
         self._packed = None          # engine.EncoderWeights, rebuilt when parameters change
         self.precision = None        # None -> LBM_AMD_PRECISION or "split"; "f32" = exact fp32 MFMA path
+        # layout of uint8 frames handed to encode_tokens: "chw" (B,3,H,W) as the reference's float frames, or a video decoder's
+        # interleaved bytes "hwc_rgb" / "hwc_bgr" (B,H,W,3) read as they are (demo_utils.py:59-66 converts on the host instead)
+        self.frame_layout = "chw"
 
     # -- weight packing -------------------------------------------------------------------------
     def _apply(self, fn, *a, **k):
@@ -92,7 +95,7 @@ class Backbone(nn.Module):
         """frames (B,3,H,W) in [0,255] → pyramid token buffer (B, L, C), level 0 = rows [0, h*w).
 
         Levels 1..3 (rows h*w..L) are filled too (average pooling, transformer.py:58-69)."""
-        return self.packed().encode(frames, out, split_out)
+        return self.packed().encode(frames, out, split_out, u8_layout=self.frame_layout)
 
     def encode_frames_online(self, frames: torch.Tensor) -> torch.Tensor:
         """backbone.py:175-193 — returns (B, h*w, C) tokens."""

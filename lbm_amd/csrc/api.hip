@@ -4,6 +4,8 @@
 
 #include <algorithm>
 #include <map>
+#include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -35,6 +37,13 @@ int check_launch(const char* what) {
     return -1;
   }
   return 0;
+}
+
+const char* intern_name(const char* s) {
+  static std::mutex mu;
+  static std::set<std::string> names;
+  std::lock_guard<std::mutex> lk(mu);
+  return names.insert(s).first->c_str();
 }
 
 // ---- per-launch timing ---------------------------------------------------------------------------
@@ -166,6 +175,18 @@ extern int g_msda_xcd;              // msda.hip (debug key 21)
 static int g_head_pair = 1;         // tuning (debug key 17): 0 = offset and visibility heads as two separate chains
 static int g_ffn_rows_mode = 0;     // tuning (debug key 15): 0 = many-rows fused feed-forward from g_ffn_fused_rows + 1 rows on, 1 = never, 2 = for any row count
 static int g_ffn_fused_rows = 2048; // tuning (debug key 7): most rows for which the feed-forward runs as one fused launch (0: never)
+
+// every knob lbm_hip_debug_set has been given, so that a measurement can state what was active (lbm_hip_debug_active)
+static std::mutex g_knob_mu;
+static std::map<int, int> g_knobs;
+static int knob_default(int key) {
+  switch (key) {
+    case 6: case 13: case 17: case 21: return 1;
+    case 7: return 2048;
+    case 8: return 63;
+    default: return 0;
+  }
+}
 
 struct TV {
   float* f = nullptr;
@@ -822,6 +843,22 @@ int lbm_hip_maxpool3x3s2_nhwc(const float* x, float* y, int32_t B, int32_t H, in
 }
 
 int lbm_hip_debug_set(int32_t key, int32_t value) {
+#ifndef LBM_TUNING
+  // The timing-only ablation switches (results are wrong when set) are compiled into the tuning build only
+  // (`make tuning`, -DLBM_TUNING): the product library refuses them instead of silently doing nothing.
+  const bool ablation = (key == 14 || key == 16 || key == 20) ? value != 0
+                        : key == 18                           ? (value & 255) != 0
+                        : key == 2                            ? (value & ~0x3b0) != 0
+                                                              : false;
+  if (ablation) {
+    set_error("debug_set: key %d value %d selects timing-only ablation code, which this library was built without (make tuning)", key, value);
+    return -1;
+  }
+#endif
+  {
+    std::lock_guard<std::mutex> lk(g_knob_mu);
+    g_knobs[key] = value;
+  }
   if (key == 9) {
     lbm::g_corr_variant = value;
     return 0;
@@ -904,6 +941,28 @@ int lbm_hip_debug_set(int32_t key, int32_t value) {
   }
   set_error("debug_set: unknown key %d", key);
   return -1;
+}
+
+int32_t lbm_hip_debug_active(int32_t* keys, int32_t* values, int32_t cap) {
+  std::lock_guard<std::mutex> lk(g_knob_mu);
+  int32_t n = 0;
+  for (const auto& kv : g_knobs) {
+    if (kv.second == knob_default(kv.first)) continue;
+    if (n < cap && keys && values) {
+      keys[n] = kv.first;
+      values[n] = kv.second;
+    }
+    ++n;
+  }
+  return n;
+}
+
+int32_t lbm_hip_tuning_build(void) {
+#ifdef LBM_TUNING
+  return 1;
+#else
+  return 0;
+#endif
 }
 
 int lbm_hip_debug_ptr(int32_t key, void* p) {
@@ -1094,11 +1153,22 @@ int lbm_hip_track_step(const lbm_hip_step_desc* d, lbm_stream_t stream) {
     st.lo = 0; st.R = (int)st.lay.R; st.sub = 0; st.nsub = 1;
     return st.run_points();
   }
-  static hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
-  if (ev_fork == nullptr) {
-    LBM_REQUIRE(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) == hipSuccess, "step: event creation failed");
-    for (int i = 0; i < 3; ++i)
-      LBM_REQUIRE(hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming) == hipSuccess, "step: event creation failed");
+  // fork / join events: one set per (calling stream), created on first use under a lock, so that two host threads driving two
+  // trackers on two streams never share (or race to create) an event
+  struct AuxEvents { hipEvent_t fork = nullptr, join[3] = {nullptr, nullptr, nullptr}; };
+  static std::mutex ev_mu;
+  static std::map<hipStream_t, AuxEvents> ev_by_stream;
+  hipEvent_t ev_fork, ev_join[3];
+  {
+    std::lock_guard<std::mutex> lk(ev_mu);
+    AuxEvents& e = ev_by_stream[(hipStream_t)stream];
+    if (e.fork == nullptr) {
+      LBM_REQUIRE(hipEventCreateWithFlags(&e.fork, hipEventDisableTiming) == hipSuccess, "step: event creation failed");
+      for (int i = 0; i < 3; ++i)
+        LBM_REQUIRE(hipEventCreateWithFlags(&e.join[i], hipEventDisableTiming) == hipSuccess, "step: event creation failed");
+    }
+    ev_fork = e.fork;
+    for (int i = 0; i < 3; ++i) ev_join[i] = e.join[i];
   }
   hipStream_t main_s = (hipStream_t)stream;
   LBM_REQUIRE(hipEventRecord(ev_fork, main_s) == hipSuccess, "step: fork record failed");

@@ -14,6 +14,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
+// Timing-only ablation switches inside kernels (they make results WRONG on purpose) exist only in the tuning build
+// (`make tuning` -> liblbm_hip_tuning.so, -DLBM_TUNING); in the product library the expression is the constant 0 and the
+// compiler drops the code behind it.  lbm_hip_debug_set refuses the corresponding keys there.
+#ifdef LBM_TUNING
+#define LBM_ABL(x) (x)
+#else
+#define LBM_ABL(x) 0
+#endif
+
 namespace lbm {
 
 // ---- error plumbing (never throw across the C ABI) --------------------------------------------
@@ -36,6 +45,9 @@ struct ProfScope {
   int slot;
   hipStream_t stream;
 };
+
+// stable storage for ProfScope names built at run time (LBM_PROF_SHAPES); safe to call from several host threads
+const char* intern_name(const char* s);
 
 // ---- cross-lane helpers (wave = 64 lanes) -----------------------------------------------------
 template <int CTRL>

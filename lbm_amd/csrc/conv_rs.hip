@@ -131,7 +131,7 @@ __global__ __launch_bounds__(512) void conv64_rows_kernel(Conv64Dev a) {
         if (k >= ns) continue;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = acx[e] = 0.f;
-        if (!(a.dbg & 4)) mac(lds + (k & (NST - 1)) * PATCH, std::integral_constant<int, 0>{});
+        if (!(LBM_ABL(a.dbg & 4))) mac(lds + (k & (NST - 1)) * PATCH, std::integral_constant<int, 0>{});
         f32x4* hb = reinterpret_cast<f32x4*>(lds + OFF_HAND + ((k & 1) * 2 + cb) * HAND) + lane;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(512) void conv64_rows_kernel(Conv64Dev a) {
           acc[4 * i] = u[0]; acc[4 * i + 1] = u[1]; acc[4 * i + 2] = u[2]; acc[4 * i + 3] = u[3];
           acx[4 * i] = v[0]; acx[4 * i + 1] = v[1]; acx[4 * i + 2] = v[2]; acx[4 * i + 3] = v[3];
         }
-        if (!(a.dbg & 8)) mac(lds + (j & (NST - 1)) * PATCH, std::integral_constant<int, 1>{});
+        if (!(LBM_ABL(a.dbg & 8))) mac(lds + (j & (NST - 1)) * PATCH, std::integral_constant<int, 1>{});
         float* Tw = reinterpret_cast<float*>(lds + OFF_FIN + ((j & 1) * 2 + cb) * FIN);
 #pragma unroll
         for (int e = 0; e < 16; ++e) Tw[(4 * h + (e & 3) + 8 * (e >> 2)) * TP + r] = (acc[e] + acx[e] * (1.0f / 2048.0f)) + bv;
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(512) void conv64_rows_kernel(Conv64Dev a) {
       if (k + 1 < ns) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");    // patch k landed, patch k + 1 may be in flight
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       handover();
-      if (k + 2 < ns && !(a.dbg & 1)) issue(k + 2);      // its stage held patch k - 2: last read in iteration k - 1
+      if (k + 2 < ns && !(LBM_ABL(a.dbg & 1))) issue(k + 2);      // its stage held patch k - 2: last read in iteration k - 1
     }
   } else {
     // ---- epilogue of step k - 2: residual, ReLU, 16-byte row pieces of the fp32 and / or split output.  The residual rows of a
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(512) void conv64_rows_kernel(Conv64Dev a) {
       constexpr int I = decltype(ic)::value;
       handover();
       fetch(ic, k);
-      if (k >= 2 && !(a.dbg & 2)) finish(std::integral_constant<int, (I + 1) % 3>{}, k - 2);
+      if (k >= 2 && !(LBM_ABL(a.dbg & 2))) finish(std::integral_constant<int, (I + 1) % 3>{}, k - 2);
     };
     for (int k = 0; k <= ns + 1; k += 3) {
       iter(std::integral_constant<int, 0>{}, k);

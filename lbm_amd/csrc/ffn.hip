@@ -288,9 +288,9 @@ __global__ __launch_bounds__(512) void ffn_rows_kernel(FfnRowsDev aa) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int rl = (e & 3) + 8 * (e >> 2) + 4 * h;
-          const float v = (aa.dbg & 1) ? sv[e] : __builtin_amdgcn_fmed3f(gelu_erf(sv[e]), -65000.f, 65000.f);
+          const float v = (LBM_ABL(aa.dbg & 1)) ? sv[e] : __builtin_amdgcn_fmed3f(gelu_erf(sv[e]), -65000.f, 65000.f);
           const _Float16 hh = (_Float16)v;
-          if (!(aa.dbg & 4)) {
+          if (!(LBM_ABL(aa.dbg & 4))) {
             Hh[rl * HP] = hh;
             Hl[rl * HP] = (_Float16)((v - (float)hh) * 2048.f);
           }
@@ -312,9 +312,9 @@ __global__ __launch_bounds__(512) void ffn_rows_kernel(FfnRowsDev aa) {
         fa[bsel][3] = *reinterpret_cast<const half8*>(Al + (2 * g + 1) * 16);
       };
       const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (!(aa.dbg & 8)) ldg(0, 0);
+      if (!(LBM_ABL(aa.dbg & 8))) ldg(0, 0);
 #pragma unroll
-      for (int g = 0; g < ((aa.dbg & 8) ? 0 : KS1 / 2); ++g) {
+      for (int g = 0; g < ((LBM_ABL(aa.dbg & 8)) ? 0 : KS1 / 2); ++g) {
         if (g + 1 < KS1 / 2) ldg((g + 1) & 1, g + 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -357,9 +357,9 @@ __global__ __launch_bounds__(512) void ffn_rows_kernel(FfnRowsDev aa) {
         fh[bsel][2] = *reinterpret_cast<const half8*>(Hh + (2 * g + 1) * 16);
         fh[bsel][3] = *reinterpret_cast<const half8*>(Hl + (2 * g + 1) * 16);
       };
-      if (!(aa.dbg & 16)) ldg(0, 0);
+      if (!(LBM_ABL(aa.dbg & 16))) ldg(0, 0);
 #pragma unroll
-      for (int g = 0; g < ((aa.dbg & 16) ? 0 : KS2 / 2); ++g) {
+      for (int g = 0; g < ((LBM_ABL(aa.dbg & 16)) ? 0 : KS2 / 2); ++g) {
         if (g + 1 < KS2 / 2) ldg((g + 1) & 1, g + 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(512) void ffn_rows_kernel(FfnRowsDev aa) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int row = m0 + (e & 3) + 8 * (e >> 2) + 4 * h;
-          if (row < a.M && !(aa.dbg & 2)) out[(long long)row * kC + col] = o[j][e] + ox[j][e] * (1.0f / 2048.0f);
+          if (row < a.M && !(LBM_ABL(aa.dbg & 2))) out[(long long)row * kC + col] = o[j][e] + ox[j][e] * (1.0f / 2048.0f);
         }
       }
     }

@@ -532,7 +532,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_ss_kernel(GemmSSDev a) {
     bx = t - by * gx;
   }
   const int m0 = by * BM, n0 = bx * BN;
-  if (a.dbg & 8) return;                                       // ablation: launch skeleton only
+  if (LBM_ABL(a.dbg & 8)) return;                                       // ablation: launch skeleton only
 
   // ---- DMA source addresses: piece p covers 16 rows of one plane; lane -> (row = lane / 4, slot = lane % 4) ----
   const _Float16* src[PPW];
@@ -607,7 +607,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_ss_kernel(GemmSSDev a) {
   const int nk = a.K / 32;
 #pragma unroll
   for (int s = 0; s < (FULL ? STAGES : STAGES - 1); ++s)
-    if ((FULL && !(a.dbg & 1)) || (!FULL && s < nk)) issue(s, s);
+    if ((FULL && !(LBM_ABL(a.dbg & 1))) || (!FULL && s < nk)) issue(s, s);
 
   // fragment byte offsets inside a plane: row * 64 + ((c ^ ((row >> 2) & 3)) * 16), c = 2 s + h
   int offA[TM][2], offB[TN][2];
@@ -672,7 +672,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_ss_kernel(GemmSSDev a) {
     // the large grids (64 -> 81 us at 16320 x 1536 x 256): the issue-to-landing latency is what the loop is exposed to.
     for (int kt = 0; kt < nk; ++kt) {
       const int pre = kt + STAGES - 1;
-      if (pre < nk && !(a.dbg & 1)) {
+      if (pre < nk && !(LBM_ABL(a.dbg & 1))) {
         issue(pre % STAGES, pre);
         wait_vmcnt<(STAGES - 1) * PPW>();        // everything but the STAGES-1 newest stages has landed
       } else {
@@ -687,7 +687,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_ss_kernel(GemmSSDev a) {
   }
 
   // ---- epilogue ----
-  if (a.dbg & 4) return;
+  if (LBM_ABL(a.dbg & 4)) return;
   float* Y = a.Y ? a.Y + z * a.sY : nullptr;
   _Float16* Yh = a.Ys ? a.Ys + z * a.sYs : nullptr;
   _Float16* Yl = a.Ys ? Yh + a.ys_plane : nullptr;
@@ -773,8 +773,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_ss_kernel(GemmSSDev a) {
         if (li[0] == bi && bi != 0x7fffffff) {          // the winner pops its head
 #pragma unroll
           for (int q = 0; q < KM - 1; ++q) {
-            lv[q] = lv[q + 1];
-            li[q] = li[q + 1];
+            float nv = lv[q + 1];
+            asm volatile("" : "+v"(nv));      // one register at a time: keeps the shift from becoming v_pk_mov_b32
+            lv[q] = nv;
+            int ni = li[q + 1];
+            asm volatile("" : "+v"(ni));
+            li[q] = ni;
           }
           lv[KM - 1] = -INFINITY;
           li[KM - 1] = 0x7fffffff;
@@ -847,7 +851,6 @@ static int launch_ss(const GemmSSDev& d, int batch, hipStream_t stream) {
                                   "," + std::to_string(WN) + "," + std::to_string(STAGES) + ">";
   const double mnk = (double)d.M * d.N * d.K * batch;
   static const bool by_shape = getenv("LBM_PROF_SHAPES") != nullptr;      // profiling aid: one entry per problem shape
-  static std::set<std::string> interned;                                  // stable storage for the names handed to ProfScope
   std::string shaped;
   if (by_shape) shaped = name + " " + std::to_string(d.M) + "x" + std::to_string(d.N) + "x" + std::to_string(d.K) + "x" + std::to_string(batch) +
                          (d.Y ? " f32" : "") + (d.Ys ? " split" : "");
@@ -859,7 +862,7 @@ static int launch_ss(const GemmSSDev& d, int batch, hipStream_t stream) {
   // keeps one column stripe per XCD there.  Debug flag 32 switches it off.
   dv.xcd_remap = !(g_dbg16 & 32) && !CONV && ((long long)grid.x * grid.y) % 8 == 0 && (long long)grid.x * grid.y >= 512 &&
                  (long long)d.N * d.K * 4 <= (2ll << 20) ? 1 : 0;
-  ProfScope prof(by_shape ? interned.insert(shaped).first->c_str() : name.c_str(), stream, 2.0 * mnk,
+  ProfScope prof(by_shape ? intern_name(shaped.c_str()) : name.c_str(), stream, 2.0 * mnk,
                  4.0 * ((double)d.M * d.K * batch + (double)d.N * d.K * (d.sB || batch == 1 ? batch : 1) +
                         (double)d.M * d.N * batch * ((d.Y ? 1 : 0) + (d.Ys ? 1 : 0) + (d.res ? 1 : 0))));
   hipLaunchKernelGGL((gemm_ss_kernel<BM, BN, WM, WN, STAGES, CONV, FULL, TOPK, NPL>), grid, dim3(WM * WN * 64), 0, stream, dv);

@@ -114,13 +114,13 @@ __global__ __launch_bounds__(512) void gemm_rs_kernel(GemmRSDev a) {
     return;
   }
   const bool active = n0 < a.Nt;                      // wave-uniform: a ragged last slice leaves waves without rows of T
-  const bool skew = ((wave >> 2) & 1) && !(a.dbg & 1);
-  const bool nt = (a.dbg & 16) != 0;    // tuning: non-temporal output stores   // waves w and w + 4 share a SIMD
+  const bool skew = ((wave >> 2) & 1) && !(LBM_ABL(a.dbg & 1));
+  const bool nt = (LBM_ABL(a.dbg & 16)) != 0;    // tuning: non-temporal output stores   // waves w and w + 4 share a SIMD
 
   // ---- stationary operand: this wave's 32 rows of T as MFMA B-fragments (lane (r, h): row r, k = 16 ks + 8 h .. + 8) ----
   half8 fbh[16], fbl[16];
-  if (a.dbg & 64) return;                 // tuning: launch skeleton only
-  if (a.dbg & 32) {                       // tuning: no loads of the stationary operand
+  if (LBM_ABL(a.dbg & 64)) return;                 // tuning: launch skeleton only
+  if (LBM_ABL(a.dbg & 32)) {                       // tuning: no loads of the stationary operand
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks)
 #pragma unroll
@@ -226,13 +226,13 @@ __global__ __launch_bounds__(512) void gemm_rs_kernel(GemmRSDev a) {
   auto epi = [&](const int step) __attribute__((always_inline)) {
     const int mb = (s0 + step) * 32;
     if constexpr (EPI == 0) {
-      if (a.dbg & 4) return;
+      if (LBM_ABL(a.dbg & 4)) return;
       float* Tw = reinterpret_cast<float*>(lds + NS * STAGE) + wave * (32 * TP);
       if (a.act == ACT_GELU) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) out[e] = gelu_erf(out[e]);
       }
-      if (!(a.dbg & 512)) {
+      if (!(LBM_ABL(a.dbg & 512))) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) Tw[(4 * h + (e & 3) + 8 * (e >> 2)) * TP + r] = out[e];
       }
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(512) void gemm_rs_kernel(GemmRSDev a) {
       // are issued from inline asm: before a compiler-visible ds_read hipcc waits vmcnt(0) here (it cannot tell the patch from the
       // DMA ring), which would drain the ring and the stores four times per step.
       f32x4 tv[4];
-      if (a.dbg & 512) {                     // tuning: no transposition (garbage goes out)
+      if (LBM_ABL(a.dbg & 512)) {                     // tuning: no transposition (garbage goes out)
 #pragma unroll
         for (int i = 0; i < 4; ++i) tv[i] = f32x4{out[4 * i], out[4 * i + 1], out[4 * i + 2], out[4 * i + 3]};
       } else {
@@ -261,9 +261,9 @@ __global__ __launch_bounds__(512) void gemm_rs_kernel(GemmRSDev a) {
       for (int i = 0; i < 4; ++i) {
         const int rl = i * 8 + (lane >> 3), c4 = lane & 7;
         const int row = mb + rl, col = n0 + c4 * 4;
-        const int srow = (a.dbg & 256) ? (row & 31) : row;     // tuning: all stores into 32 rows (L2-resident)
+        const int srow = (LBM_ABL(a.dbg & 256)) ? (row & 31) : row;     // tuning: all stores into 32 rows (L2-resident)
         float4 v = make_float4(tv[i][0], tv[i][1], tv[i][2], tv[i][3]);
-        if (row < a.Ms && col < a.Nt && !(a.dbg & 1024)) {   // (1024: tuning, transposition without the stores)
+        if (row < a.Ms && col < a.Nt && !(LBM_ABL(a.dbg & 1024))) {   // (1024: tuning, transposition without the stores)
           if (RES && res) {
             int rr = row;
             if (a.res_div != 1) rr /= a.res_div;
@@ -315,25 +315,25 @@ __global__ __launch_bounds__(512) void gemm_rs_kernel(GemmRSDev a) {
     // The counter retires in issue order, so "at most NST + 4 outstanding" means step s is in while those stay in flight.  Waves
     // without columns issue no stores; with a residual the compiler's own waits for the residual loads drain the queue anyway.
     const bool more = s + 1 < ns;
-    if (s >= 2 && active && !RES && NST > 0 && !(a.dbg & 128)) {
+    if (s >= 2 && active && !RES && NST > 0 && !(LBM_ABL(a.dbg & 128))) {
       if (more) wait_vm<NST + 4>();
       else wait_vm<NST>();
     } else {
       if (more) wait_vm<4>();
       else wait_vm<0>();
     }
-    if (!(a.dbg & 2048)) __builtin_amdgcn_s_barrier();          // every wave's pieces of step s are in; every wave is done reading step s - 1
+    if (!(LBM_ABL(a.dbg & 2048))) __builtin_amdgcn_s_barrier();          // every wave's pieces of step s are in; every wave is done reading step s - 1
     const unsigned char* Ab = lds + (s % NS) * STAGE;
-    const bool mm = active && !(a.dbg & 8);
+    const bool mm = active && !(LBM_ABL(a.dbg & 8));
     if (mm) ldg(Ab, 0, 0);                 // in flight under the epilogue / DMA issue below
     if (!skew) {
       if (active && s > 0) epi(s - 1);
-      if (s + 2 < ns && !(a.dbg & 2)) issue((s + 2) % NS, s + 2);
+      if (s + 2 < ns && !(LBM_ABL(a.dbg & 2))) issue((s + 2) % NS, s + 2);
     }
     if (mm) half_step(Ab, 0);
     if (skew) {
       if (active && s > 0) epi(s - 1);
-      if (s + 2 < ns && !(a.dbg & 2)) issue((s + 2) % NS, s + 2);
+      if (s + 2 < ns && !(LBM_ABL(a.dbg & 2))) issue((s + 2) % NS, s + 2);
     }
     if (mm) half_step(Ab, 4);
     if (active) {
@@ -403,13 +403,12 @@ int gemm_rs(const GemmSSArgs& a, int dbg, hipStream_t stream) {
   const long long wgs = rs_grid(d);
   LBM_REQUIRE(wgs <= 0x7fffffffLL, "gemm_rs: grid too large");
   static const bool by_shape = getenv("LBM_PROF_SHAPES") != nullptr;
-  static std::set<std::string> interned;      // stable storage for the names handed to ProfScope
   std::string shaped;
   if (by_shape)
     shaped = "gemm_rs " + std::to_string(a.M) + "x" + std::to_string(a.N) + "x" + std::to_string(a.K) + "x" + std::to_string(a.batch) +
              (a.Y ? " f32" : "") + (a.Ys ? " split" : "");
   const double mnk = (double)a.M * a.N * a.K * a.batch;
-  ProfScope prof(by_shape ? interned.insert(shaped).first->c_str() : "gemm_rs", stream, 2.0 * mnk,
+  ProfScope prof(by_shape ? intern_name(shaped.c_str()) : "gemm_rs", stream, 2.0 * mnk,
                  4.0 * ((double)a.M * a.K * a.batch + (double)a.N * a.K * (a.sB || a.batch == 1 ? a.batch : 1) +
                         (double)a.M * a.N * a.batch * ((a.Y ? 1 : 0) + (a.Ys ? 1 : 0) + (a.res ? 1 : 0))));
   const dim3 grid((unsigned)wgs), block(512);

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(512) void stem_pool_kernel(StemDev a) {
     const int fo = 16 * r + 16 * h;          // byte offset of this lane's fragment inside an input row (+ 32 for the second half of the taps)
     for (int t = 0; t <= n + 1; ++t) {
       handover();
-      if (t > n || (t == n && rp == 1) || (a.dbg & 4)) continue;      // (conv row B of the last iteration belongs to the next workgroup)
+      if (t > n || (t == n && rp == 1) || (LBM_ABL(a.dbg & 4))) continue;      // (conv row B of the last iteration belongs to the next workgroup)
       const unsigned char* Pb = lds + (t & (NST - 1)) * PATCH + (2 * rp) * ROWB + fo;
       f32x16 acc, acx;
 #pragma unroll
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(512) void stem_pool_kernel(StemDev a) {
         __builtin_amdgcn_sched_barrier(0);
       }
       float* Tw = reinterpret_cast<float*>(lds + OFF_FIN + (((t & 1) * 2 + rp) * 2 + cb) * FIN);
-      if (!(a.dbg & 8))
+      if (!(LBM_ABL(a.dbg & 8)))
 #pragma unroll
         for (int e = 0; e < 16; ++e) Tw[(4 * h + (e & 3) + 8 * (e >> 2)) * TP + r] = fmaxf((acc[e] + acx[e] * (1.0f / 2048.0f)) + bv, 0.f);
     }
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(512) void stem_pool_kernel(StemDev a) {
       if (t + 1 <= n) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");     // patch t landed, patch t + 1 may be in flight
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       handover();
-      if (t + 2 <= n && !(a.dbg & 1)) issue(t + 2);            // its stage held patch t - 2: last read in iteration t - 2
+      if (t + 2 <= n && !(LBM_ABL(a.dbg & 1))) issue(t + 2);            // its stage held patch t - 2: last read in iteration t - 2
     }
   } else {
     // ---- pooling.  Iteration t takes conv rows A = 2 (py0 + k) - 1 and B = 2 (py0 + k) of iteration k = t - 1: pooled row
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(512) void stem_pool_kernel(StemDev a) {
     auto mx = [](const float4 p, const float4 q) { return make_float4(fmaxf(p.x, q.x), fmaxf(p.y, q.y), fmaxf(p.z, q.z), fmaxf(p.w, q.w)); };
     for (int t = 0; t <= n + 1; ++t) {
       handover();
-      if (t == 0 || (a.dbg & 2)) continue;
+      if (t == 0 || (LBM_ABL(a.dbg & 2))) continue;
       const int k = t - 1;
       const float* Ta = reinterpret_cast<const float*>(lds + OFF_FIN + (((k & 1) * 2 + 0) * 2 + cb) * FIN);
       const float* Tb = reinterpret_cast<const float*>(lds + OFF_FIN + (((k & 1) * 2 + 1) * 2 + cb) * FIN);

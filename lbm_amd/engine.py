@@ -139,12 +139,16 @@ class EncoderWeights:
                 os.environ.get("LBM_AMD_FUSED_STEM", "1") != "0")
 
     def encode(self, frames: torch.Tensor, out: Optional[torch.Tensor] = None,
-               split_out: Optional["hip.SplitTensor"] = None) -> torch.Tensor:
-        """split_out: caller-owned split twin to fill instead of the encoder's own (double-buffered pipelines)."""
+               split_out: Optional["hip.SplitTensor"] = None, u8_layout: str = "chw") -> torch.Tensor:
+        """split_out: caller-owned split twin to fill instead of the encoder's own (double-buffered pipelines).
+        u8_layout: how a uint8 frame is laid out ("chw" (B,3,H,W); "hwc_rgb" / "hwc_bgr" (B,H,W,3), a video decoder's bytes as
+        they are); float frames are always (B,3,H,W)."""
         self._split_target = split_out
+        if frames.dtype != torch.uint8:
+            u8_layout = "chw"
         if self._fused_stem:
-            return self._body_split(hip.preprocess_split(frames, self.size[0], self.size[1]), True, out)
-        x = hip.preprocess(frames, self.size[0], self.size[1], layout=4)
+            return self._body_split(hip.preprocess_split(frames, self.size[0], self.size[1], u8_layout), True, out)
+        x = hip.preprocess(frames, self.size[0], self.size[1], layout=4, u8_layout=u8_layout)
         return self._body(x, True, out)
 
     def encode_normalised(self, x_nchw: torch.Tensor, add_pos: bool = True) -> torch.Tensor:
@@ -481,8 +485,9 @@ class TrackEngine:
             # the following ones).  The cache holds the tensor itself, so "the same query" means the same object at the same
             # version: its memory cannot have been handed to another tensor in between.
             qc = self._qc
-            if qc is None or qc["ref"] is not query or qc["ver"] != query._version or qc["prec"] != d.precision:
-                qc = self._qc = {"ref": query, "ver": query._version, "prec": d.precision, "split": None, "u0": None, "u0_valid": 0}
+            qver = hip.tensor_version(query)
+            if qc is None or qc["ref"] is not query or qc["ver"] != qver or qc["prec"] != d.precision:
+                qc = self._qc = {"ref": query, "ver": qver, "prec": d.precision, "split": None, "u0": None, "u0_valid": 0}
             if d.precision >= 1:
                 if qc["split"] is None:
                     qs = hip.SplitTensor(tuple(query.shape), dev)

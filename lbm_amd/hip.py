@@ -30,7 +30,7 @@ EXPORTS = (
     "lbm_hip_update_points", "lbm_hip_encoder_tail", "lbm_hip_pack_fragment_major", "lbm_hip_ffn_slabs",
     "lbm_hip_debug_ptr", "lbm_hip_update_points_static", "lbm_hip_preprocess_u8", "lbm_hip_corr_topk",
     "lbm_hip_corr_topk_workspace_bytes", "lbm_hip_preprocess_split", "lbm_hip_stem_pool",
-    "lbm_hip_encoder_tail_fused",
+    "lbm_hip_encoder_tail_fused", "lbm_hip_debug_active", "lbm_hip_tuning_build",
 )
 
 
@@ -162,6 +162,10 @@ def load() -> C.CDLL:
     lib.lbm_hip_split_planes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.lbm_hip_profile_end.argtypes = [C.POINTER(ProfileEntry), C.c_int32]
     lib.lbm_hip_debug_ptr.argtypes = [C.c_int32, C.c_void_p]
+    lib.lbm_hip_debug_set.argtypes = [C.c_int32, C.c_int32]
+    lib.lbm_hip_debug_active.argtypes = [C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32]
+    lib.lbm_hip_debug_active.restype = C.c_int32
+    lib.lbm_hip_tuning_build.restype = C.c_int32
     lib.lbm_hip_preprocess_split.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_int64] + [C.c_int32] * 5 + [C.c_void_p]
     lib.lbm_hip_stem_pool.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                       C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
@@ -173,6 +177,30 @@ def load() -> C.CDLL:
                                       C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = lib
     return lib
+
+
+def tensor_version(t: torch.Tensor):
+    """The tensor's in-place version counter, or None for tensors created under torch.inference_mode() (they do not track one:
+    in-place edits of such a tensor are then not detected by the caches keyed on it)."""
+    return None if t.is_inference() else t._version
+
+
+def frame_hw(frames: torch.Tensor, u8_layout: str = "chw") -> Tuple[int, int]:
+    """(H, W) of a batch of frames: (B,3,H,W), or (B,H,W,3) for uint8 frames in an interleaved layout."""
+    if frames.dtype == torch.uint8 and u8_layout != "chw":
+        return int(frames.shape[-3]), int(frames.shape[-2])
+    return int(frames.shape[-2]), int(frames.shape[-1])
+
+
+def debug_active() -> Dict[int, int]:
+    """Knobs of lbm_hip_debug_set that differ from their defaults right now: {key: value}."""
+    lib = load()
+    n = int(lib.lbm_hip_debug_active(None, None, 0))
+    if n == 0:
+        return {}
+    keys, vals = (C.c_int32 * n)(), (C.c_int32 * n)()
+    n = min(n, int(lib.lbm_hip_debug_active(keys, vals, n)))
+    return {int(keys[i]): int(vals[i]) for i in range(n)}
 
 
 def _check(rc: int, what: str) -> None:

@@ -59,6 +59,21 @@ class LBM_online(LBM):
             from .object_tracker import LBMObjTracker
             self.objtracker = LBMObjTracker(args)
 
+    @property
+    def frame_layout(self) -> str:
+        """Layout of uint8 frames: "chw" (B,3,H,W) (default), "hwc_rgb" or "hwc_bgr" (B,H,W,3) -- a decoder's bytes as they are,
+        a quarter of the float frame's bytes; float frames are always (B,3,H,W) as in the reference."""
+        return self.backbone.frame_layout
+
+    @frame_layout.setter
+    def frame_layout(self, v: str) -> None:
+        if v not in hip.U8_LAYOUTS:
+            raise ValueError(f"frame_layout must be one of {sorted(hip.U8_LAYOUTS)}")
+        self.backbone.frame_layout = v
+
+    def _hw(self, frames: torch.Tensor):
+        return hip.frame_hw(frames, self.backbone.frame_layout)
+
     # ---- logical (oldest-first) views of the ring state, reference layout (1|B, N, M, ...) ----
     def _logical(self, x: Optional[torch.Tensor]):
         if x is None:
@@ -107,7 +122,7 @@ class LBM_online(LBM):
         self.query_points = query_points
         self.N = query_points.shape[0]
         self.B = 1
-        self.img_size = first_frame.shape[-2:]
+        self.img_size = self._hw(first_frame)
         self.device = first_frame.device
         self.t = 0
         self.query = None
@@ -159,7 +174,7 @@ class LBM_online(LBM):
         """query_points (B,N,2) xy frame pixels; first_frames (B,3,H,W).  B independent streams, one state."""
         B, N = query_points.shape[:2]
         self.B, self.N = B, N
-        self.img_size = first_frames.shape[-2:]
+        self.img_size = self._hw(first_frames)
         self.device = first_frames.device
         self.t = 0
         self.query_points = query_points
@@ -171,7 +186,8 @@ class LBM_online(LBM):
     @staticmethod
     def _frame_key(frames: torch.Tensor):
         # address, geometry and the tensor's version counter: an in-place write to the frame after prefetch() changes the key
-        return (frames.data_ptr(), tuple(frames.shape), tuple(frames.stride()), frames.dtype, frames._version)
+        # (tensors created under torch.inference_mode() have no version counter: edits of those are not detected)
+        return (frames.data_ptr(), tuple(frames.shape), tuple(frames.stride()), frames.dtype, hip.tensor_version(frames))
 
     @torch.no_grad()
     def prefetch(self, frames: torch.Tensor) -> None:
@@ -208,7 +224,7 @@ class LBM_online(LBM):
         # frames back) was enqueued there as well: one wait covers both
         enc.wait_stream(main)
         frames.record_stream(enc)
-        H, W = frames.shape[-2], frames.shape[-1]
+        H, W = self._hw(frames)
         with torch.cuda.stream(enc):
             if p["tok_s"][slot] is None and self.backbone.packed().precision in ("split", "f16"):
                 p["tok_s"][slot] = hip.SplitTensor(tuple(p["tok"][slot].shape), frames.device)
@@ -221,14 +237,17 @@ class LBM_online(LBM):
         self._pf[self._frame_key(frames)] = slot
 
     @torch.no_grad()
-    def online_forward_batch(self, frames: torch.Tensor, tokens: Optional[torch.Tensor] = None):
+    def online_forward_batch(self, frames: torch.Tensor, tokens: Optional[torch.Tensor] = None, out=None):
         """frames (B,3,H,W) -> coords (B,N,2) frame px, vis (B,N) bool, rho (B,N) in (0,1), tokens (B,L,C).
+
+        ``out``: optional dict of caller-owned result tensors ("coords" (B,N,2), "vis", "rho", "rho_prob" (B,N) fp32, "offset"
+        (B,N,2), "vis_flag" (B,N) bool) the step writes instead of allocating -- e.g. slices of a whole-run track log.
 
         Lifetime of the returned tokens: for a frame that was encoded ahead (prefetch) they are a VIEW of one of the two
         pipeline slots and are overwritten by the prefetch after next; a caller that keeps them longer (e.g. for a later
         update()) passes ``tokens=`` and gets a copy there -- the reference returns a fresh tensor every frame
         (lbm_online.py:125-126).  Unpipelined frames return a fresh tensor (or ``tokens`` itself)."""
-        H, W = frames.shape[-2], frames.shape[-1]
+        H, W = self._hw(frames)
         if self._pf:
             slot = self._pf.pop(self._frame_key(frames), None)
             if slot is None and len(self._pf) > 1:
@@ -243,7 +262,7 @@ class LBM_online(LBM):
                 out = self.transformer.get_engine().step(tok, self.query, self._stream, self._coll, self._vis, self._mem,
                                                          ring_head=self._head, queried=None, update_state=True, img_hw=(H, W),
                                                          vis_threshold=self.visibility_treshold,
-                                                         tokens_split=p["tok_s"][slot], phase=2, ws_slot=slot)
+                                                         tokens_split=p["tok_s"][slot], phase=2, ws_slot=slot, out=out)
                 self._head = (self._head + 1) % self.memory_size
                 self.t += 1
                 self.last_logits = (out["vis"], out["rho"])
@@ -253,7 +272,7 @@ class LBM_online(LBM):
                 return out["coords"], out["vis_flag"], out["rho_prob"], tok
         if self._pipe is not None:      # the encoder's scratch is shared: never run it on two streams at once
             torch.cuda.current_stream().wait_stream(self._pipe["stream"])
-        if self.use_graph and frames.is_cuda and self.B * self.N <= self.graph_max_rows and self.N > 0:
+        if self.use_graph and out is None and frames.is_cuda and self.B * self.N <= self.graph_max_rows and self.N > 0:
             res = self._forward_graph(frames)
             if res is not None:
                 return res
@@ -264,7 +283,7 @@ class LBM_online(LBM):
         out = self.transformer.get_engine().step(tok, self.query, self._stream, self._coll, self._vis, self._mem,
                                                  ring_head=self._head, queried=None, update_state=True, img_hw=(H, W),
                                                  vis_threshold=self.visibility_treshold,
-                                                 tokens_split=self.backbone.last_tokens_split, ws_slot=ws_slot)
+                                                 tokens_split=self.backbone.last_tokens_split, ws_slot=ws_slot, out=out)
         self._head = (self._head + 1) % self.memory_size
         self.t += 1
         self.last_logits = (out["vis"], out["rho"])
@@ -272,11 +291,11 @@ class LBM_online(LBM):
 
     def _forward_graph(self, frames: torch.Tensor):
         """Replay (capturing on first use) the HIP graph of this frame step; None = not available, run eagerly."""
-        key = (tuple(frames.shape), self.N, self.memory_size, self._stream.data_ptr(), self.query.data_ptr(), self.query._version,
+        key = (tuple(frames.shape), self.N, self.memory_size, self._stream.data_ptr(), self.query.data_ptr(), hip.tensor_version(self.query),
                float(self.visibility_treshold), self.transformer.precision, self.backbone.precision)
         if self._gkey != key:
             self._graphs, self._gkey, self._eager_done = {}, key, False
-            self._g_in = torch.empty_like(frames, dtype=torch.float32)
+            self._g_in = torch.empty_like(frames)            # same dtype and layout: uint8 frames stay uint8
             L = self.transformer.cfg.num_tokens
             self._g_tok = torch.empty(frames.shape[0], L, self.embed_dim, device=frames.device, dtype=torch.float32)
             self._g_fork = torch.cuda.Event()
@@ -285,7 +304,7 @@ class LBM_online(LBM):
             # the first frame of a configuration runs eagerly: it packs weights and sizes every persistent buffer
             self._eager_done = True
             return None
-        H, W = frames.shape[-2], frames.shape[-1]
+        H, W = self._hw(frames)
         self._g_in.copy_(frames)
         head = self._head
         if head not in self._graphs:
@@ -337,7 +356,7 @@ class LBM_online(LBM):
             remove_mask = self.objtracker.points_remove_mask.flatten()        # (M' * npt,) tracklets before the drop
             query_points = memo[4].reshape(-1, 2)
             if self.N == 0:          # nothing was tracked yet: this frame has not been encoded
-                self.img_size = frame.shape[-2:]
+                self.img_size = self._hw(frame)
                 self.device = frame.device
                 tok = self.backbone.encode_tokens(frame)
             self.update(query_points, tok, update_mask, remove_mask)

@@ -20,11 +20,38 @@ def _rng(seed: int, name: str) -> np.random.Generator:
     return np.random.Generator(np.random.PCG64(int.from_bytes(digest[:8], "little")))
 
 
-def synthetic_state_dict(model: torch.nn.Module, seed: int = 42) -> Dict[str, torch.Tensor]:
+def _smooth_field(g: np.random.Generator, shape: Tuple[int, ...], passes: int) -> np.ndarray:
+    """White noise over the last two axes low-passed by `passes` rounds of the separable [1, 2, 1] / 4 filter (edges clamped) and
+    rescaled to unit standard deviation: neighbouring cells are alike, cells a few steps apart are not.  Plain numpy adds in a
+    fixed order, so the field is the same on every machine."""
+    v = g.normal(0.0, 1.0, shape)
+    for _ in range(passes):
+        for ax in (-2, -1):
+            lo = np.concatenate([np.take(v, [0], axis=ax), np.take(v, range(v.shape[ax] - 1), axis=ax)], axis=ax)
+            hi = np.concatenate([np.take(v, range(1, v.shape[ax]), axis=ax), np.take(v, [v.shape[ax] - 1], axis=ax)], axis=ax)
+            v = 0.25 * lo + 0.5 * v + 0.25 * hi
+    return v / v.std()
+
+
+PRESETS = ("flat", "peaked")
+
+
+def synthetic_state_dict(model: torch.nn.Module, seed: int = 42, preset: str = "flat") -> Dict[str, torch.Tensor]:
     """A full state dict for ``model`` (any module tree with lbm.pt-style names) with non-degenerate values:
     Kaiming-scale convolutions, Xavier-scale linears, N(0, 0.02) embeddings, BatchNorm statistics around
     (0, 1) +- 10 %, and **non-zero** deformable-attention offset / weight projections (the default init zeroes
-    them, msdeformattn.py:76-79, which would leave the gather path untested)."""
+    them, msdeformattn.py:76-79, which would leave the gather path untested).
+
+    preset "flat" (the default, what every golden fixture and bench figure was made with): encoder content (token norm ~80,
+    most of it one direction shared by every cell) swamps the N(0, 0.02) positional embedding, so every correlation row is
+    nearly flat -- best cell 1.64-1.65 against a row median of 1.57, median gap between the k-th and (k+1)-th value 1e-3 --
+    and the arg-max (transformer.py:306-313), the thing that moves a track by >= 4 px, is decided by near-ties.
+    preset "peaked": what a trained tracker's rows look like -- one smooth bump around the point's cell.  The positional
+    embedding is a low-passed random field of unit variance (neighbouring cells alike, cells three apart unrelated) and the
+    fusion BatchNorm gain is cut to 5 %, so a token is its cell's signature plus a little frame content: the query's own
+    cell wins by ~0.1 and the k best cells are its neighbourhood, ranked by distance from the query's sub-cell position."""
+    if preset not in PRESETS:
+        raise ValueError(f"preset must be one of {PRESETS}")
     out: Dict[str, torch.Tensor] = {}
     for name, t in model.state_dict().items():
         g = _rng(seed, name)
@@ -33,7 +60,11 @@ def synthetic_state_dict(model: torch.nn.Module, seed: int = 42) -> Dict[str, to
         if t.dtype in (torch.int64, torch.int32):
             out[name] = t.detach().clone().cpu()          # spatial_shapes / start_levels / num_batches_tracked
             continue
-        if leaf == "running_mean":
+        if preset == "peaked" and "frame_pos_embedding" in name:
+            v = _smooth_field(g, shape, passes=2)
+        elif preset == "peaked" and name.endswith(("fusion.1.weight", "fusion.1.bias")):
+            v = 0.05 * (g.normal(1.0, 0.1, shape) if leaf == "weight" else g.normal(0.0, 0.05, shape))
+        elif leaf == "running_mean":
             v = g.normal(0.0, 0.1, shape)
         elif leaf == "running_var":
             v = g.uniform(0.9, 1.1, shape)

@@ -164,3 +164,55 @@ def test_ctypes_argument_lists_match_the_c_prototypes():
         assert len(fn.argtypes) == n, f"{name}: header has {n} parameters, hip.py declares {len(fn.argtypes)}"
         checked += 1
     assert checked >= 30
+
+
+def test_product_library_refuses_the_timing_only_ablation_knobs():
+    """Keys 14 / 16 / 18 (bits 0-7) / 20 and bits 12.. of key 2 switch parts of kernels OFF for timing (results are wrong by design);
+    that code exists only in the -DLBM_TUNING build.  The product library must refuse them with an error -- not accept and ignore --
+    and lbm_hip_debug_active must list exactly the knobs that differ from their defaults (what bench.py prints in `config.knobs`)."""
+    from lbm_amd import hip
+    lib = hip.load()
+    if lib.lbm_hip_tuning_build():
+        pytest.skip("LBM_AMD_LIB points at a tuning build")
+    assert hip.debug_active() == {}
+    for key, value in ((14, 1), (16, 8), (18, 2), (20, 4), (2, 1 << 12), (2, 4)):
+        assert lib.lbm_hip_debug_set(key, value) == -1, (key, value)
+        assert b"ablation" in lib.lbm_hip_last_error()
+    assert hip.debug_active() == {}
+    try:
+        assert lib.lbm_hip_debug_set(18, 4 << 8) == 0          # steps per workgroup of conv64_rows: a real tuning knob, results unchanged
+        assert lib.lbm_hip_debug_set(2, 256) == 0
+        assert lib.lbm_hip_debug_set(21, 0) == 0
+        assert lib.lbm_hip_debug_set(17, 1) == 0               # its default: not "active"
+        assert hip.debug_active() == {18: 4 << 8, 2: 256, 21: 0}
+    finally:
+        for key, value in ((18, 0), (2, 0), (21, 1)):
+            lib.lbm_hip_debug_set(key, value)
+    assert hip.debug_active() == {}
+    assert lib.lbm_hip_debug_set(99, 1) == -1
+
+
+def test_inference_mode_tensors_do_not_break_the_frame_and_query_keys():
+    """Tensors created under torch.inference_mode() have no version counter (reading ._version raises); the keys that use it
+    (LBM_online._frame_key for prefetch, the engine's per-query cache, the graph key) fall back to None for them."""
+    from lbm_amd import hip
+    from lbm_amd.lbm_online import LBM_online
+    with torch.inference_mode():
+        f = torch.zeros(1, 3, 8, 8)
+        assert hip.tensor_version(f) is None
+        key = LBM_online._frame_key(f)
+        assert key[-1] is None and key[1] == (1, 3, 8, 8)
+    g = torch.zeros(1, 3, 8, 8)
+    v0 = hip.tensor_version(g)
+    g.add_(1)
+    assert hip.tensor_version(g) == v0 + 1
+    assert LBM_online._frame_key(g)[-1] == v0 + 1
+
+
+def test_frame_geometry_follows_the_declared_layout():
+    from lbm_amd import hip
+    assert hip.frame_hw(torch.zeros(2, 3, 48, 64)) == (48, 64)
+    assert hip.frame_hw(torch.zeros(2, 3, 48, 64, dtype=torch.uint8)) == (48, 64)
+    assert hip.frame_hw(torch.zeros(2, 48, 64, 3, dtype=torch.uint8), "hwc_rgb") == (48, 64)
+    assert hip.frame_hw(torch.zeros(2, 48, 64, 3, dtype=torch.uint8), "hwc_bgr") == (48, 64)
+    assert hip.frame_hw(torch.zeros(2, 3, 48, 64), "hwc_rgb") == (48, 64)      # float frames are always (B,3,H,W)

@@ -8,6 +8,11 @@ k-th and (k+1)-th best value 1e-3), so some selections are numerical ties: torch
 a different cell moves the track by >= 4 px.  A point is therefore allowed to leave the comparison -- for the rest of the
 run, its memories differ from then on -- only if the ORACLE's own k / (k+1) gap fell below 1e-4 in some layer of this or an
 earlier frame; any other disagreement fails, and so does losing more than 10 % of the points that way.
+
+Because such rows barely exercise the arg-max, both workloads run a second time on the "peaked" synthetic checkpoint
+(lbm_amd/synth.py: one smooth bump per correlation row, the query's own cell ahead by ~0.1, median k / (k+1) gap 3e-2), where
+at most 1 % of the points may leave.  Every test prints how many points the tie rule dropped and how many ties the oracle saw
+(also appended to gpurun_out/parity_drops.txt when that directory exists) -- the allowance is a bound, the count is the result.
 """
 import numpy as np
 import pytest
@@ -18,14 +23,26 @@ from oracle import lbm_ref_cpu as ref
 pytestmark = pytest.mark.gpu
 
 COORD_TOL, LOGIT_TOL, TIE = 0.05, 1e-3, 1e-4
+ALLOW = {"flat": 0.10, "peaked": 0.01}          # share of the compared points the tie rule may remove, per checkpoint preset
 
 
-def _model(M):
+def _report(tag, streams):
+    import os
+    n = sum(len(o.dropped) for o in streams)
+    line = (f"{tag}: {sum(int(o.dropped.sum()) for o in streams)} of {n} compared points dropped by the tie rule "
+            f"({sum(int(o.tie_seen.sum()) for o in streams)} had an oracle k/(k+1) gap < {TIE:g} at some layer and frame)")
+    print(line)
+    if os.path.isdir("gpurun_out"):
+        with open("gpurun_out/parity_drops.txt", "a") as f:
+            f.write(line + "\n")
+
+
+def _model(M, preset="flat"):
     from lbm_amd.config import LBMConfig
     from lbm_amd.lbm_online import LBM_online
     from lbm_amd.synth import synthetic_state_dict
     model = LBM_online(LBMConfig(input_size=(384, 512), memory_size=12).to_namespace())
-    sd = synthetic_state_dict(model, seed=42)
+    sd = synthetic_state_dict(model, seed=42, preset=preset)
     model.load_state_dict(sd, strict=True)
     model = model.cuda().eval()
     g = ref.Geometry(size=(384, 512), memory_size=12)
@@ -39,7 +56,8 @@ def _model(M):
 class _OracleStream:
     """RefOnline (lbm_online.py:27-158 restated) plus the book-keeping of the tie rule in the header."""
 
-    def __init__(self, sd, g, pts, first_frame):
+    def __init__(self, sd, g, pts, first_frame, allow=ALLOW["flat"]):
+        self.allow = allow
         self.o = ref.RefOnline(sd, g)
         self.o.init(pts, first_frame)
         self.tie_seen = torch.zeros(pts.shape[0], dtype=torch.bool)
@@ -67,14 +85,15 @@ class _OracleStream:
                                              f"(coords by up to {float((got_c.cpu() - c).abs().amax(-1)[unexplained].max()):.3f} px) "
                                              f"with no tie in the oracle's own selection")
         self.dropped |= off
-        assert self.dropped.float().mean() <= 0.10, f"{tag}: {int(self.dropped.sum())} of {len(off)} points lost to ties"
+        assert self.dropped.float().mean() <= self.allow, f"{tag}: {int(self.dropped.sum())} of {len(off)} points lost to ties (allowed {self.allow:.0%})"
 
     @property
     def stable(self):
         return ~self.dropped
 
 
-def test_c3_64_streams_of_256_points_against_the_oracle_and_against_single_streams():
+@pytest.mark.parametrize("preset", ["flat", "peaked"])
+def test_c3_64_streams_of_256_points_against_the_oracle_and_against_single_streams(preset):
     """BASELINE config 3: init_streams / online_forward_batch at B = 64 x N = 256 on 480x854 frames, 3 tracked frames.
     Streams 0, 31 and 63 against the oracle; stream 31 also against the same stream tracked alone (B = 1)."""
     from lbm_amd.synth import random_queries, synthetic_video
@@ -82,9 +101,9 @@ def test_c3_64_streams_of_256_points_against_the_oracle_and_against_single_strea
     base = synthetic_video(T, H, W, seed=42)[0]
     video = torch.stack([torch.roll(base, shifts=(3 * s) % W, dims=-1) if s else base for s in range(B)], 0)     # (B,T,3,H,W)
     pts = torch.stack([random_queries(N, H, W, 42 + s) for s in range(B)], 0)
-    model, sd, g = _model(12)
+    model, sd, g = _model(12, preset)
     vid = video.cuda()
-    got = []
+    got, oracles = [], []
     with torch.no_grad():
         model.init_streams(pts.cuda(), vid[:, 0].contiguous())
         for t in range(1, T):
@@ -92,14 +111,16 @@ def test_c3_64_streams_of_256_points_against_the_oracle_and_against_single_strea
             got.append((c.clone(), model.last_logits[0].clone(), model.last_logits[1].clone(), v.clone()))
         assert model.stream_dist.shape == (B, N, 12, 256)
         for s in (0, 31, 63):
-            o = _OracleStream(sd, g, pts[s], video[s, :1])
+            o = _OracleStream(sd, g, pts[s], video[s, :1], ALLOW[preset])
+            oracles.append(o)
             for t in range(1, T):
                 want = o.step(video[s, t:t + 1])
                 o.check(f"stream {s} frame {t}", got[t - 1][0][s], got[t - 1][1][s], got[t - 1][2][s], want)
                 vis_ok = (torch.sigmoid(want[1]) - 0.8).abs() > 2e-3
                 assert (got[t - 1][3][s].cpu() == (torch.sigmoid(want[1]) > 0.8))[vis_ok & o.stable].all()
+        _report(f"c3 {preset}", oracles)
         # the same stream alone: different tile shapes and K splits, same arithmetic to rounding
-        single, _, _ = _model(12)
+        single, _, _ = _model(12, preset)
         single.init(pts[31].cuda(), vid[31, :1].contiguous())
         for t in range(1, T):
             c1, v1, r1, _ = single.online_forward(vid[31, t:t + 1].contiguous())
@@ -109,7 +130,8 @@ def test_c3_64_streams_of_256_points_against_the_oracle_and_against_single_strea
             assert (single.last_logits[0][0] - got[t - 1][1][31]).abs()[ok].max() < LOGIT_TOL
 
 
-def test_c5_1080p_dense_grid_long_memory_against_the_oracle_on_sampled_points():
+@pytest.mark.parametrize("preset", ["flat", "peaked"])
+def test_c5_1080p_dense_grid_long_memory_against_the_oracle_on_sampled_points(preset):
     """BASELINE config 5: 1080x1920, 100x100 grid = 10 000 points, set_memory_size(48), 52 tracked frames so the ring wraps.
     64 sampled points against the oracle every frame; properties of the full point set; the fused top-k correlation product
     (taken from 4096 rows on) is what actually ran."""
@@ -119,11 +141,11 @@ def test_c5_1080p_dense_grid_long_memory_against_the_oracle_on_sampled_points():
     video = synthetic_video(NF + 1, H, W, seed=42)                         # (1, 7, 3, H, W); tracked frames cycle through 6
     pts = grid_queries(H, W, 100)
     sel = torch.linspace(0, pts.shape[0] - 1, 64).long()
-    model, sd, g = _model(M)
+    model, sd, g = _model(M, preset)
     vid = video.cuda()
     with torch.no_grad():
         model.init(pts.cuda(), vid[:, 0].contiguous())
-        o = _OracleStream(sd, g, pts[sel], video[:, 0])
+        o = _OracleStream(sd, g, pts[sel], video[:, 0], ALLOW[preset])
         for t in range(T):
             f = 1 + t % NF
             if t == 3:
@@ -140,6 +162,7 @@ def test_c5_1080p_dense_grid_long_memory_against_the_oracle_on_sampled_points():
             # the slot written this frame: memory mask cleared, visibility mask = sigmoid(vis) < 0.8 (lbm_online.py:145-146)
             assert not bool(model.mem_mask[0, :, -1].any())
             assert torch.equal(model.vis_mask[0, :, -1], torch.sigmoid(model.last_logits[0][0]) < 0.8)
+        _report(f"c5 {preset}", [o])
         assert model.t == T and not bool(model.mem_mask.any())              # every one of the 48 slots has been written
         _check_state = (model.stream_dist[0, sel.cuda()].cpu() - o.o.state.stream[0]).abs().amax((-1, -2))
         assert _check_state[o.stable].max() < 5e-3

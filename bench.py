@@ -55,6 +55,11 @@ F16_MFMA_PEAK_TF = 2500.0    # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak (th
                              # flops per algorithmic flop, so their ceiling in algorithmic TFLOP/s is a third of it)
 
 
+PRESET_LABEL = {
+    "flat": "seeded synthetic lbm.pt-layout checkpoint, preset 'flat' (nearly flat correlation rows: the k best cells of a point lie anywhere on the map)",
+    "peaked": "seeded synthetic lbm.pt-layout checkpoint, preset 'peaked' (one smooth bump per correlation row, as a trained tracker's: the k best "
+              "cells are a neighbourhood of the point)",
+}
 PRECISION_LABEL = {
     "split": "fp32 operands as split f16 hi/lo planes on the f16 matrix cores, fp32 accumulate (fp32-grade, passes the 1e-4 / 0.05 px parity bars)",
     "f32": "exact fp32 MFMA",
@@ -62,13 +67,13 @@ PRECISION_LABEL = {
 }
 
 
-def build_model(wl, device):
+def build_model(wl, device, preset="flat"):
     from lbm_amd.config import LBMConfig
     from lbm_amd.lbm_online import LBM_online
     from lbm_amd.synth import synthetic_state_dict
     cfg = LBMConfig(input_size=(384, 512), memory_size=12)
     model = LBM_online(cfg.to_namespace())
-    sd = synthetic_state_dict(model, seed=42)
+    sd = synthetic_state_dict(model, seed=42, preset=preset)
     model.load_state_dict(sd, strict=True)
     model = model.to(device).eval()
     if wl["M"] != 12:
@@ -143,7 +148,7 @@ def roofline_of(prof, steps_profiled):
         peak = F32_MFMA_PEAK_TF if f32 else F16_MFMA_PEAK_TF
         roof = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
                 "mfma_flops_per_algorithmic_flop": 1 if (f32 or dom["name"].startswith(("gemm_sh", "conv_sh", "ffn_fused_sh"))) else 3}
-    elif dom["name"].startswith("msda_sample"):
+    elif dom["name"].startswith(("msda_sample", "msda_window")):
         # a gather out of a 16.7 MB map that every workgroup shares: served by the L2s, not by HBM -- priced against the
         # guide's L2 shared-row rate, reported under bound "hbm" would exceed 1
         ach = dom["bytes"] / sec / 1e9
@@ -167,9 +172,9 @@ def roofline_of(prof, steps_profiled):
 class Runner:
     """One workload on this rank's GPU: model, resident frames, the serial / pipelined frame loops and a state snapshot."""
 
-    def __init__(self, wl, rank, device):
+    def __init__(self, wl, rank, device, preset="flat"):
         self.wl = wl
-        self.model, self.sd = build_model(wl, device)
+        self.model, self.sd = build_model(wl, device, preset)
         self.video_cpu, self.pts_cpu = make_inputs(wl, rank)
         video = self.video_cpu.to(device)                  # (B,T,3,H,W) resident in HBM
         self.pts = self.pts_cpu.to(device)
@@ -302,7 +307,7 @@ def _attach_traffic(roof, prof, wname):
             roof["algorithmic_bytes_per_launch"] = dom["bytes"] / max(dom["launches"], 1)
 
 
-def measure_throughput(name, steps, warmup, rank, device, sync, profile=True, precision=None):
+def measure_throughput(name, steps, warmup, rank, device, sync, profile=True, precision=None, preset="flat"):
     """One entry of `workloads`: the same Runner.time_loops as the headline (so `--workload c3` and `workloads.c3` are the same
     measurement up to the step count), plus the roofline entry of its dominant kernel."""
     w2 = WORKLOADS[name]
@@ -310,7 +315,7 @@ def measure_throughput(name, steps, warmup, rank, device, sync, profile=True, pr
     if precision is not None:
         os.environ["LBM_AMD_PRECISION"] = precision
     try:
-        r2 = Runner(w2, rank, device)
+        r2 = Runner(w2, rank, device, preset)
         e_s, e_p, same2, _ = r2.time_loops(steps, warmup, sync)
         prof2 = r2.profile(4) if profile else []
         roof2, kern2 = roofline_of(prof2, 4)
@@ -323,7 +328,7 @@ def measure_throughput(name, steps, warmup, rank, device, sync, profile=True, pr
             else:
                 os.environ["LBM_AMD_PRECISION"] = old
     fl = step_flops(w2, r2.N, r2.B)
-    ent = {"workload": w2["desc"], "steps": steps, "ms_per_step": 1e3 * e_s / steps,
+    ent = {"workload": w2["desc"], "weights": PRESET_LABEL[preset], "steps": steps, "ms_per_step": 1e3 * e_s / steps,
            "value": float(r2.B) * r2.N * steps / e_s, "unit": "point-frames/s",
            "dtype": "f16" if precision in ("f16", "f16s") else "f32",
            "step_algorithmic_TFLOPs": fl / (e_s / steps) / 1e12,
@@ -386,6 +391,8 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--preset", default="flat", choices=["flat", "peaked"], help="synthetic checkpoint preset (lbm_amd/synth.py); the headline "
+                    "figures of every round were taken on 'flat'")
     ap.add_argument("--allow-knobs", action="store_true", help="tuning run with lbm_hip_debug_set knobs off their defaults (LBM_DEBUG_SET) "
                     "or a -DLBM_TUNING library: the line carries headline_valid = false")
     args = ap.parse_args()
@@ -442,7 +449,7 @@ def main():
     from lbm_amd.sharding import gather_tracks, max_over_ranks, pack_tracks
     cdev = device if args.backend == "nccl" else torch.device("cpu")
     with torch.no_grad():
-        r = Runner(wl, rank, device)
+        r = Runner(wl, rank, device, args.preset)
         B, N = r.B, r.N
         el_serial, el_pipe, same, (coords, vis, rho) = r.time_loops(args.steps, args.warmup, barrier, want_pipeline)
         my_serial, my_pipe = el_serial, el_pipe
@@ -488,7 +495,11 @@ def main():
             del r
             torch.cuda.empty_cache()
             for name, steps in (("c3", 12), ("c5", 30)):
-                extra[name] = measure_throughput(name, steps, 4, rank, device, local_sync, not args.no_profile)
+                extra[name] = measure_throughput(name, steps, 4, rank, device, local_sync, not args.no_profile, preset=args.preset)
+                # the same workload on the other checkpoint preset: where the reference cells of a point lie decides how much of
+                # the deformable sampling the LDS window catches (and how often the fused top-k inserts)
+                other = "peaked" if args.preset == "flat" else "flat"
+                extra[f"{name}_{other}"] = measure_throughput(name, steps, 4, rank, device, local_sync, not args.no_profile, preset=other)
             for name in ("c1", "c1_10"):
                 extra[name] = measure_clicks(name, rank, device, cpu=(name == "c1" and not args.no_cpu_baseline))
     headline_pipelined = el_pipe is not None and same and el_pipe < el_serial
@@ -505,7 +516,7 @@ def main():
             "metric": "point-frames/sec (whole node) dense-grid tracking; p50 per-frame latency",
             "value": total_pf / elapsed, "unit": "point-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16" if prec in ("f16", "f16s") else "f32", "data": "synthetic (seeded video, seeded lbm.pt-layout weights)",
+            "dtype": "f16" if prec in ("f16", "f16s") else "f32", "data": f"synthetic (seeded video, seeded lbm.pt-layout weights, preset '{args.preset}')",
             "config": {"workload": f"{wname}: {wl['desc']}", "streams_per_gpu": B, "points_per_stream": N,
                        "memory_size": wl["M"], "frame": [wl["H"], wl["W"]], "frame_pipeline": mode_txt,
                        "precision": PRECISION_LABEL[prec], "parallelism": f"streams x{world} (no collective in the step)",

@@ -7,7 +7,7 @@ With seeded random weights the correlation maps are nearly flat (best cell 1.64.
 k-th and (k+1)-th best value 1e-3), so some selections are numerical ties: torch.topk's order among them is unspecified and
 a different cell moves the track by >= 4 px.  A point is therefore allowed to leave the comparison -- for the rest of the
 run, its memories differ from then on -- only if the ORACLE's own k / (k+1) gap fell below 1e-4 in some layer of this or an
-earlier frame; any other disagreement fails, and so does losing more than 10 % of the points that way.
+earlier frame; any other disagreement fails, and so does losing more than 2 % of the points that way (measured: none, profiles/r03_parity_drops.txt).
 
 Because such rows barely exercise the arg-max, both workloads run a second time on the "peaked" synthetic checkpoint
 (lbm_amd/synth.py: one smooth bump per correlation row, the query's own cell ahead by ~0.1, median k / (k+1) gap 3e-2), where
@@ -23,7 +23,7 @@ from oracle import lbm_ref_cpu as ref
 pytestmark = pytest.mark.gpu
 
 COORD_TOL, LOGIT_TOL, TIE = 0.05, 1e-3, 1e-4
-ALLOW = {"flat": 0.10, "peaked": 0.01}          # share of the compared points the tie rule may remove, per checkpoint preset
+ALLOW = {"flat": 0.02, "peaked": 0.01}          # share of the compared points the tie rule may remove, per checkpoint preset
 
 
 def _report(tag, streams):

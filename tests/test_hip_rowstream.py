@@ -285,3 +285,57 @@ def test_msda_xcd_aware_order_gives_the_same_rows(hip, B, N, k, P):
         lib.lbm_hip_debug_set(21, 1)
     assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))
     assert bool(torch.isfinite(outs[1]).all()) and float(outs[1].abs().max()) > 0
+
+
+@pytest.mark.parametrize("B,N,k,spread,off_scale,shapes", [
+    (1, 70, 9, "block", 1.0, [(96, 128), (48, 64), (24, 32), (12, 16)]),        # 3 x 3 neighbourhood, small offsets: everything in the window
+    (1, 70, 9, "block", 6.0, [(96, 128), (48, 64), (24, 32), (12, 16)]),        # large learned offsets: part of the taps outside the window
+    (1, 64, 9, "scattered", 2.0, [(96, 128), (48, 64), (24, 32), (12, 16)]),    # flat correlation row: cells anywhere, nothing staged
+    (1, 64, 4, "block", 2.0, [(96, 128), (48, 64), (24, 32), (12, 16)]),        # layer 1: 2 x 2 cells
+    (1, 33, 4, "mixed", 3.0, [(16, 24), (8, 12), (4, 6), (2, 3)]),              # tiny maps: the window is the whole coarse level
+    (16, 9, 9, "mixed", 2.0, [(16, 24), (8, 12), (4, 6), (2, 3)]),              # a batch of streams: XCD-aware order of the point workgroups
+    (1, 40, 9, "edge", 2.5, [(96, 128), (48, 64), (24, 32), (12, 16)]),         # reference cells on the map border: zero-padded taps
+])
+def test_msda_window_kernel_gives_the_direct_kernels_rows(hip, B, N, k, spread, off_scale, shapes):
+    """The LDS-staged form of msda_sample (k = 9 / 4 lattice launches: one workgroup per point, window of value cells staged per level
+    and head, taps worked out once per (cell, sample)) against the direct gather (debug key 22 = 0): every output row bit for bit --
+    clustered reference cells, scattered ones, offsets that leave the window, map borders."""
+    lib = hip.load()
+    g = torch.Generator(device="cpu").manual_seed(B * 1000 + N * 10 + k + int(off_scale * 7))
+    h0, w0 = shapes[0]
+    net_w, net_h = 4.0 * w0, 4.0 * h0
+    L = sum(h * w for h, w in shapes)
+    P = 9
+    value = torch.randn(B, L, 256, generator=g).cuda()
+    offlog = torch.randn(B * N, 48 * P, generator=g)
+    offlog[:, :32 * P] *= off_scale
+    offlog = offlog.cuda()
+    R = B * N
+    centre = torch.rand(R, 1, 2, generator=g) * torch.tensor([net_w, net_h])
+    if spread == "edge":
+        centre = centre * torch.tensor([1.0, 0.02])                          # top rows of the map
+        centre[::2] = torch.tensor([net_w - 1.0, net_h - 1.0]) - centre[::2] * torch.tensor([0.02, 1.0])
+    side = 3 if k == 9 else 2
+    cells = torch.stack([torch.tensor([float(i % side), float(i // side)]) for i in range(k)], 0) * 4.0     # neighbouring cells, 4 px apart
+    block = (centre // 4.0) * 4.0 + 2.0 + cells.unsqueeze(0)
+    scattered = torch.rand(R, k, 2, generator=g) * torch.tensor([net_w, net_h])
+    if spread == "scattered":
+        ref = scattered
+    elif spread == "mixed":
+        ref = torch.where((torch.arange(R) % 3 == 0).view(R, 1, 1), scattered, block)
+        ref[1::3, -1] = scattered[1::3, -1]                                  # one outlier cell beside a neighbourhood
+    else:
+        ref = block
+    ref = ref.cuda().contiguous()
+    outs = []
+    try:
+        for mode in (0, 1):
+            lib.lbm_hip_debug_set(22, mode)
+            hip.profile_begin()
+            outs.append(hip.msda_sample(value, shapes, offlog, ref, B, N, k, P, net_w, net_h))
+            names = {p["name"] for p in hip.profile_end()}
+            assert names == ({"msda_window"} if mode else {"msda_sample"}), names
+    finally:
+        lib.lbm_hip_debug_set(22, 1)
+    assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))
+    assert bool(torch.isfinite(outs[1]).all()) and float(outs[1].abs().max()) > 0

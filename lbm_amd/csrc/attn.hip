@@ -20,7 +20,15 @@
 namespace lbm {
 
 // sum p[0..15] over the 64 lanes; afterwards tot[q] (wave-uniform) holds the total of p[q]
+__device__ __forceinline__ float reduce16_lane(const float (&p)[16], int lane);
 __device__ __forceinline__ void reduce16(const float (&p)[16], float (&tot)[16], int lane) {
+  const float a1 = reduce16_lane(p, lane);
+  // lane with bits (5,4,3,2) = (q3,q2,q1,q0) holds the total of index q = 8 q3 + 4 q2 + 2 q1 + q0
+#pragma unroll
+  for (int q = 0; q < 16; ++q) tot[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a1), q << 2));
+}
+// the same, left where the butterfly puts it: lane L holds the total of index (L >> 2) & 15
+__device__ __forceinline__ float reduce16_lane(const float (&p)[16], int lane) {
   float a8[8], a4[4], a2[2], a1;
   const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
 #pragma unroll
@@ -32,22 +40,23 @@ __device__ __forceinline__ void reduce16(const float (&p)[16], float (&tot)[16],
   a1 = (b2 ? a2[1] : a2[0]) + __shfl_xor(b2 ? a2[0] : a2[1], 4);
   a1 += __shfl_xor(a1, 2);
   a1 += __shfl_xor(a1, 1);
-  // lane with bits (5,4,3,2) = (q3,q2,q1,q0) holds the total of index q = 8 q3 + 4 q2 + 2 q1 + q0
-#pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const int srcl = ((q & 8) ? 32 : 0) | ((q & 4) ? 16 : 0) | ((q & 2) ? 8 : 0) | ((q & 1) ? 4 : 0);
-    tot[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a1), srcl));
-  }
+  return a1;
 }
 
-template <int WPP, bool TEMB>
+// XL: the group's exponentials evaluated across the lanes (see the loop); false = every lane evaluates all twenty (the first form,
+// kept for the bit-identity test: debug key 3, value + 16)
+template <int WPP, bool TEMB, bool XL = true>
 __global__ __launch_bounds__(256) void attn_readout_kernel(AttnArgs a) {
   __shared__ float sm_acc[WPP == 1 ? 1 : 4][LBM_HEADS][LBM_C];
   __shared__ float sm_ml[WPP == 1 ? 1 : 4][2][LBM_HEADS];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int row = WPP == 1 ? blockIdx.x * 4 + wave : blockIdx.x;
-  if (row >= a.R) return;
+  // WPP waves share a point (4 / WPP points per workgroup); sub = this wave's place among them
+  const int row_ = blockIdx.x * (4 / WPP) + wave / WPP;
+  const int sub = wave % WPP;
+  if (WPP == 1 && row_ >= a.R) return;
+  const bool live = row_ < a.R;                    // (WPP > 1: a wave past the end works on the last row and stores nothing --
+  const int row = live ? row_ : a.R - 1;           //  every wave of the workgroup reaches the barrier of the merge)
 
   float4 u[LBM_HEADS];
 #pragma unroll
@@ -58,6 +67,7 @@ __global__ __launch_bounds__(256) void attn_readout_kernel(AttnArgs a) {
   const uint8_t* mb = a.mask_b ? a.mask_b + (long long)row * a.S : nullptr;
 
   float m[LBM_HEADS], l[LBM_HEADS];
+  float m_lane = -INFINITY;                      // m[(lane >> 2) & 3], kept per lane for the group soft-max
   float4 acc[LBM_HEADS];
 #pragma unroll
   for (int hh = 0; hh < LBM_HEADS; ++hh) {
@@ -72,7 +82,7 @@ __global__ __launch_bounds__(256) void attn_readout_kernel(AttnArgs a) {
   // would have to return before the slot's row load could be issued behind it (loads retire in order), which
   // serialised the whole read-out.  A group never straddles a 64-slot chunk (4·WPP divides 64).
   const int step = WPP;
-  const int jb0 = WPP == 1 ? 0 : wave;
+  const int jb0 = sub;
   unsigned long long ign = 0;
   int ign_chunk = -1;
   auto load_masks = [&](int chunk) {
@@ -119,6 +129,43 @@ __global__ __launch_bounds__(256) void attn_readout_kernel(AttnArgs a) {
 #pragma unroll
       for (int hh = 0; hh < LBM_HEADS; ++hh) p[g * 4 + hh] = u[hh].x * kx.x + u[hh].y * kx.y + u[hh].z * kx.z + u[hh].w * kx.w;
     }
+    if constexpr (XL) {
+    // Soft-max bookkeeping of the group.  The 16 scores come out of the butterfly one per lane quad (lane L: slot (L >> 4) & 3,
+    // head (L >> 2) & 3), so the 16 weights exp(s - max) and the 4 rescale factors exp(m_old - max) are TWO exponentials
+    // evaluated across the lanes and then broadcast as scalars -- not twenty evaluated by all 64 lanes alike, which made the
+    // kernel instruction-bound (~450 vector instructions per 4 KB of memory read) rather than HBM-bound.  Same values, same
+    // order of the sums: bit-identical.
+    const float sl = reduce16_lane(p, lane);
+    const int gl = (lane >> 4) & 3;
+    const bool use_l = gl == 0 ? use[0] : (gl == 1 ? use[1] : (gl == 2 ? use[2] : use[3]));
+    float mx = use_l ? sl : -INFINITY;
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float mn_l = fmaxf(m_lane, mx);             // running maximum of this lane's head
+    const float w_l = expf(sl - mn_l);
+    const float sc_l = expf(m_lane - mn_l);           // m = -inf -> 0
+    m_lane = mn_l;
+    auto bcast = [](float x, int src) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), src)); };
+#pragma unroll
+    for (int hh = 0; hh < LBM_HEADS; ++hh) {
+      const float mn = bcast(mn_l, hh << 2);
+      if (mn == -INFINITY) continue;             // nothing attended so far (wave-uniform)
+      const float sc = bcast(sc_l, hh << 2);
+      float ls = l[hh] * sc;
+      float4 ac = make_float4(acc[hh].x * sc, acc[hh].y * sc, acc[hh].z * sc, acc[hh].w * sc);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if (use[g]) {                            // wave-uniform: masks are per (row, slot)
+          const float w = bcast(w_l, (g << 4) | (hh << 2));
+          ls += w;
+          ac.x += w * v[g].x; ac.y += w * v[g].y; ac.z += w * v[g].z; ac.w += w * v[g].w;
+        }
+      }
+      m[hh] = mn;
+      l[hh] = ls;
+      acc[hh] = ac;
+    }
+    } else {
     float s[16];
     reduce16(p, s, lane);
 #pragma unroll
@@ -143,9 +190,10 @@ __global__ __launch_bounds__(256) void attn_readout_kernel(AttnArgs a) {
       l[hh] = ls;
       acc[hh] = ac;
     }
+    }
   }
 
-  if (WPP > 1) {   // merge the four waves' online-softmax states
+  if (WPP > 1) {   // merge the online-softmax states of the point's WPP waves (in wave order: fixed summation order)
 #pragma unroll
     for (int hh = 0; hh < LBM_HEADS; ++hh) {
       st4(&sm_acc[wave][hh][lane * 4], acc[hh]);
@@ -155,22 +203,22 @@ __global__ __launch_bounds__(256) void attn_readout_kernel(AttnArgs a) {
       }
     }
     __syncthreads();
-    if (wave != 0) return;
+    if (sub != 0 || !live) return;
 #pragma unroll
     for (int hh = 0; hh < LBM_HEADS; ++hh) {
       float mm = -INFINITY;
 #pragma unroll
-      for (int w2 = 0; w2 < 4; ++w2) mm = fmaxf(mm, sm_ml[w2][0][hh]);
+      for (int w2 = 0; w2 < WPP; ++w2) mm = fmaxf(mm, sm_ml[wave + w2][0][hh]);
       float ls = 0.f;
       float4 ac = make_float4(0.f, 0.f, 0.f, 0.f);
       if (mm != -INFINITY) {
 #pragma unroll
-        for (int w2 = 0; w2 < 4; ++w2) {
-          const float mw = sm_ml[w2][0][hh];
+        for (int w2 = 0; w2 < WPP; ++w2) {
+          const float mw = sm_ml[wave + w2][0][hh];
           if (mw == -INFINITY) continue;
           const float sc = expf(mw - mm);
-          ls += sm_ml[w2][1][hh] * sc;
-          const float4 q = ld4(&sm_acc[w2][hh][lane * 4]);
+          ls += sm_ml[wave + w2][1][hh] * sc;
+          const float4 q = ld4(&sm_acc[wave + w2][hh][lane * 4]);
           ac.x += q.x * sc; ac.y += q.y * sc; ac.z += q.z * sc; ac.w += q.w * sc;
         }
       }
@@ -191,7 +239,7 @@ __global__ __launch_bounds__(256) void attn_readout_kernel(AttnArgs a) {
   if (a.valid && lane == 0) a.valid[row] = l[0] > 0.f ? 1 : 0;
 }
 
-static int g_attn_mode = 0;   // tuning knob: 0 auto, 1 = one wave per point, 4 = four waves per point
+static int g_attn_mode = 0;   // tuning knob (debug key 3): 0 auto, 1 = one wave per point, 2 = two, 4 = four waves per point; + 16 = every lane evaluates every exponential
 void attn_force_mode(int m) { g_attn_mode = m; }
 
 int attn_readout(const AttnArgs& a, hipStream_t stream) {
@@ -204,14 +252,22 @@ int attn_readout(const AttnArgs& a, hipStream_t stream) {
   // algorithmic traffic: the S sequence rows once, 4 per-head queries in, 4 per-head read-outs out, the masks
   ProfScope prof("attn_readout", stream, (double)a.R * a.S * 4.0 * LBM_C * 4,
                  (double)a.R * (4.0 * LBM_C * (a.S + 8) + (a.mask_a ? a.S : 0) + (a.mask_b ? a.S : 0)));
-  const bool wide = g_attn_mode == 4 || (g_attn_mode == 0 && a.R < 4096 && a.S >= 8);
-  if (wide) {
-    if (a.temb) hipLaunchKernelGGL((attn_readout_kernel<4, true>), dim3(a.R), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((attn_readout_kernel<4, false>), dim3(a.R), dim3(256), 0, stream, a);
+  const int mode = g_attn_mode & 15;
+  const bool wide = mode == 4 || (mode == 0 && a.R < 4096 && a.S >= 8);
+  // two waves per point (forced with debug key 3 = 2 only): measured no faster than one at 10 000 points x 48 or 96 slots
+  // (124.1 against 121.7 us, 224 against 222), so the automatic choice never takes it
+  const bool pair = !wide && mode == 2 && !(g_attn_mode & 16);
+  const dim3 grid(wide ? a.R : pair ? (a.R + 1) / 2 : (a.R + 3) / 4);
+#define LBM_ATTN_LAUNCH(W, T, X) hipLaunchKernelGGL((attn_readout_kernel<W, T, X>), grid, dim3(256), 0, stream, a)
+  if (g_attn_mode & 16) {      // the first form of the soft-max step (bit-identity test)
+    if (wide) { if (a.temb) LBM_ATTN_LAUNCH(4, true, false); else LBM_ATTN_LAUNCH(4, false, false); }
+    else { if (a.temb) LBM_ATTN_LAUNCH(1, true, false); else LBM_ATTN_LAUNCH(1, false, false); }
   } else {
-    if (a.temb) hipLaunchKernelGGL((attn_readout_kernel<1, true>), dim3((a.R + 3) / 4), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((attn_readout_kernel<1, false>), dim3((a.R + 3) / 4), dim3(256), 0, stream, a);
+    if (wide) { if (a.temb) LBM_ATTN_LAUNCH(4, true, true); else LBM_ATTN_LAUNCH(4, false, true); }
+    else if (pair) { if (a.temb) LBM_ATTN_LAUNCH(2, true, true); else LBM_ATTN_LAUNCH(2, false, true); }
+    else { if (a.temb) LBM_ATTN_LAUNCH(1, true, true); else LBM_ATTN_LAUNCH(1, false, true); }
   }
+#undef LBM_ATTN_LAUNCH
   return check_launch("attn_readout");
 }
 

@@ -50,6 +50,7 @@ struct TailArgs {
   int ldw1;
   const float* b1;
   float* inv;           // [B, L] or null: 1 / max(|row|, 1e-12) of every token row written here (what corr_maps would compute)
+  int stream_minor;     // workgroup order: 1 = the same 8 x 8 block of every stream back to back (they share its rows of `pos`), 0 = stream by stream
 };
 
 // F.normalize's factor for one 256-channel row held by a wave (lane = 4 channels); every rounding spelled out: the encoder tail and
@@ -81,8 +82,11 @@ __global__ __launch_bounds__(NW * 64) void pyramid_pool_kernel(float* __restrict
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int bw = w >> 3, bh = h >> 3;
   const int P0 = h * w;
-  const int b = blockIdx.x / (bh * bw);
-  const int rem = blockIdx.x - b * (bh * bw);
+  // Stream-minor order for a batch of streams: the 64 rows of the positional embedding a block adds are the same for every
+  // stream; stream by stream they come back after a whole stream's worth of other rows has passed through the L2.
+  const bool sm_order = TAIL && ta.stream_minor;
+  const int b = sm_order ? blockIdx.x % B : blockIdx.x / (bh * bw);
+  const int rem = sm_order ? blockIdx.x / B : blockIdx.x - b * (bh * bw);
   const int by = rem / bw, bx = rem - by * bw;
   float* base = tok + (long long)b * L * LBM_C + lane * 4;
   const long long sbase = (long long)b * L * LBM_C + lane * 4;
@@ -249,6 +253,8 @@ int encoder_tail(const float* q1, const float* q2, const float* q3, const float*
   return check_launch("encoder_tail");
 }
 
+int g_tail_order = 1;   // debug key 24: 0 = workgroups of the fused encoder tail stream by stream
+
 // encoder_tail with the finest level's 64 -> 256 product inside: f1 split planes [B, h*w, 64], W1 split [256, ldw1], b1 [256] or null
 int encoder_tail_fused(const void* f1, long long f1_plane, const void* w1h, const void* w1l, int ldw1, const float* b1, const float* q2,
                        const float* q3, const float* pos, float* tokens, int B, int h, int w, hipStream_t stream, void* toks,
@@ -265,6 +271,7 @@ int encoder_tail_fused(const void* f1, long long f1_plane, const void* w1h, cons
   TailArgs ta{};
   ta.q2 = q2; ta.q3 = q3; ta.pos = pos;
   ta.f1 = (const _Float16*)f1; ta.f1_plane = f1_plane; ta.w1h = (const _Float16*)w1h; ta.w1l = (const _Float16*)w1l; ta.ldw1 = ldw1; ta.b1 = b1; ta.inv = inv_norm;
+  ta.stream_minor = (g_tail_order && pos != nullptr && B >= 8) ? 1 : 0;
   if (blocks >= 512) hipLaunchKernelGGL((pyramid_pool_kernel<2, 8>), dim3((unsigned)blocks), dim3(512), 0, stream, tokens, B, h, w, L, toks, toks_plane, ta);
   else hipLaunchKernelGGL((pyramid_pool_kernel<2, 16>), dim3((unsigned)blocks), dim3(1024), 0, stream, tokens, B, h, w, L, toks, toks_plane, ta);
   return check_launch("encoder_tail_fused");

@@ -250,10 +250,17 @@ def test_attention_readout_long_sequences(hip, S, head):
     lib = hip.load()
     try:
         for mode in (1, 4):
+            # + 16: the soft-max step with every lane evaluating every exponential (the first form of the kernel); the shipped
+            # form evaluates them across the lanes and must give the same bits
+            lib.lbm_hip_debug_set(3, mode + 16)
+            old, _ = hip.attn_readout(torch.from_numpy(U).cuda(), torch.from_numpy(seq).cuda(), S, ring_head=head,
+                                      temb=torch.from_numpy(temb).cuda(), mask_a=torch.from_numpy(ma).cuda().to(torch.uint8),
+                                      mask_b=torch.from_numpy(mb).cuda().to(torch.uint8), want_valid=True)
             lib.lbm_hip_debug_set(3, mode)
             got, v = hip.attn_readout(torch.from_numpy(U).cuda(), torch.from_numpy(seq).cuda(), S, ring_head=head,
                                       temb=torch.from_numpy(temb).cuda(), mask_a=torch.from_numpy(ma).cuda().to(torch.uint8),
                                       mask_b=torch.from_numpy(mb).cuda().to(torch.uint8), want_valid=True)
+            assert torch.equal(got.view(torch.int32), old.view(torch.int32)), f"mode {mode}: cross-lane soft-max differs from the first form"
             assert (v.bool().cpu().numpy() == valid).all(), f"mode {mode}"
             err = np.abs(got.cpu().numpy().astype(np.float64) - want).max()
             assert err < 2e-5, f"mode {mode}: {err}"

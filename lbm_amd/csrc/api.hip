@@ -184,7 +184,8 @@ static std::mutex g_knob_mu;
 static std::map<int, int> g_knobs;
 static int knob_default(int key) {
   switch (key) {
-    case 6: case 13: case 17: case 21: case 22: case 24: return 1;
+    case 6: case 13: case 17: case 21: case 24: return 1;
+    case 22: return 3;
     case 7: return 2048;
     case 8: return 63;
     default: return 0;

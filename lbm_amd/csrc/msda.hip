@@ -378,9 +378,95 @@ __global__ __launch_bounds__(64 * HPW) void msda_window_kernel(MsdaArgs a) {
   }
 }
 
+// ---- single reference cell (k = 1: last layer, the three heads) with the taps worked out once --------------------------------
+// The direct kernel has all 64 lanes redo every sample's address arithmetic (~45 vector instructions per sample, the bound of
+// that kernel); here lane = sample does it once, parks (cell, weight) per tap in LDS, and the gather loop is a table read, a
+// load and four multiply-adds per sample.  Same expressions, same order of the sums: bit-identical rows.  One wave (= head) per
+// workgroup, or HPW of them; two-module launches (set_rows) as in the direct kernel.
+template <int PT, int HPW>
+__global__ __launch_bounds__(64 * HPW) void msda_taps_kernel(MsdaArgs a) {
+  constexpr int S = LBM_LEVELS * PT;
+  constexpr int WPP = LBM_HEADS / HPW;
+  __shared__ int2 meta_all[HPW][S * 4];
+  const int lane = threadIdx.x & 63;
+  const int hw = threadIdx.x >> 6;
+  long long rq = blockIdx.x / WPP;                 // output row
+  int hg = (int)(blockIdx.x % WPP);
+  if (a.xcd_streams) {
+    const int c = (int)(blockIdx.x & 7);
+    const long long t = blockIdx.x >> 3;
+    const long long per = (long long)a.N * WPP;
+    const long long j = t / per;
+    const long long u = t - j * per;
+    rq = (j * 8 + c) * a.N + u / WPP;              // (two-module launches: unit j * 8 + c runs over (module, stream))
+    hg = (int)(u % WPP);
+  }
+  const int hd = hg * HPW + hw;
+  int2* meta = meta_all[hw];
+  const int set = (a.set_rows != 0 && rq >= a.set_rows) ? 1 : 0;
+  const long long r = rq - (long long)set * a.set_rows;
+  const int b = (int)(r / a.N);
+  {
+    float dx = 0.f, dy = 0.f, logit = -INFINITY;
+    int l = 0;
+    if (lane < S) {
+      l = lane / PT;
+      const float* o = a.offlog + r * a.ld_offlog + set * a.set_offlog_off;
+      const int oi = (hd * S + lane) * 2;
+      dx = o[oi] / (float)sel4(a.lvl_w, l);
+      dy = o[oi + 1] / (float)sel4(a.lvl_h, l);
+      logit = o[a.logit_col + hd * S + lane];
+    }
+    const float* rp = a.ref + r * 2;
+    const float rx = fminf(fmaxf(rp[0] / a.net_w, 0.f), 1.f);
+    const float ry = fminf(fmaxf(rp[1] / a.net_h, 0.f), 1.f);
+    const float mx = wave_max(logit);
+    const float e = lane < S ? expf(logit - mx) : 0.f;
+    const float wt = e / wave_sum(e);
+    if (lane < S) {
+      const int hl = sel4(a.lvl_h, l), wl = sel4(a.lvl_w, l), st = sel4(a.lvl_start, l);
+      const float lx = rx + dx, ly = ry + dy;
+#pragma unroll
+      for (int t4 = 0; t4 < 4; ++t4) {
+        const Tap t = bilinear_tap(lx, ly, wt, wl, hl, t4 & 1, t4 >> 1);
+        meta[lane * 4 + t4] = make_int2(st + t.yc * wl + t.xc, __float_as_int(t.tw));
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const int tap = lane >> 4, cq = lane & 15;
+  const float* vb = a.value + (long long)b * a.v_batch_stride + set * a.set_value_off + hd * LBM_HD + cq * 4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 1
+  for (int i0 = 0; i0 < S; i0 += PT) {
+    int2 m[PT];
+#pragma unroll
+    for (int p = 0; p < PT; ++p) m[p] = meta[(i0 + p) * 4 + tap];
+    float4 v[PT];
+#pragma unroll
+    for (int p = 0; p < PT; ++p) v[p] = ld4(vb + (long long)m[p].x * a.ldv);
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+      const float tw = __int_as_float(m[p].y);
+      acc.x += tw * v[p].x;
+      acc.y += tw * v[p].y;
+      acc.z += tw * v[p].z;
+      acc.w += tw * v[p].w;
+    }
+  }
+  acc.x += __shfl_xor(acc.x, 16); acc.y += __shfl_xor(acc.y, 16); acc.z += __shfl_xor(acc.z, 16); acc.w += __shfl_xor(acc.w, 16);
+  acc.x += __shfl_xor(acc.x, 32); acc.y += __shfl_xor(acc.y, 32); acc.z += __shfl_xor(acc.z, 32); acc.w += __shfl_xor(acc.w, 32);
+  if (lane < 16) {
+    const long long oo = rq * LBM_C + hd * LBM_HD + cq * 4;
+    if (a.out) st4(a.out + oo, acc);
+    if (a.out_s) st4_split(a.out_s, a.out_plane, oo, acc);
+  }
+}
+
 int g_msda_xcd = 1;   // debug key 21: 0 = dispatch order
 int g_msda_dbg = 0;      // debug key 23 (tuning build): ablation bits of the window kernel
-int g_msda_window = 1;   // debug key 22: 0 = always the direct kernel; 1 (default) = LDS-staged kernel for the k = 9 / 4 lattice launches
+int g_msda_window = 3;   // debug key 22, bits: 1 = LDS-staged kernel for the k = 9 / 4 lattice launches, 2 = tap-table kernel for k = 1; 0 = always the direct kernel (default 3)
 
 int msda_sample(const MsdaArgs& a, hipStream_t stream) {
   const long long R = (long long)a.B * a.N;
@@ -400,8 +486,9 @@ int msda_sample(const MsdaArgs& a, hipStream_t stream) {
   // algorithmic traffic per query: 4 heads x 4 levels x P points x 4 taps x 64 channels read (L2/MALL-resident maps),
   // one 256-channel row written
   const double nq = (double)R * a.k * (a.set_rows ? 2 : 1);
-  const bool use_window = !explicit_mode && g_msda_window && a.set_rows == 0 && a.P == 9 && (a.k == 9 || a.k == 4);
-  ProfScope prof(use_window ? "msda_window" : "msda_sample", stream, nq * 16.0 * a.P * 4 * 64 * 2, nq * (16.0 * a.P * 4 * 64 * 4 + 4.0 * LBM_C));
+  const bool use_window = !explicit_mode && (g_msda_window & 1) && a.set_rows == 0 && a.P == 9 && (a.k == 9 || a.k == 4);
+  const bool use_taps = !explicit_mode && (g_msda_window & 2) && a.k == 1 && (a.P == 9 || a.P == 4);
+  ProfScope prof(use_window ? "msda_window" : use_taps ? "msda_taps" : "msda_sample", stream, nq * 16.0 * a.P * 4 * 64 * 2, nq * (16.0 * a.P * 4 * 64 * 4 + 4.0 * LBM_C));
   if (explicit_mode) {
     LBM_REQUIRE(a.attw != nullptr && a.k == 1, "msda_sample: explicit mode needs attw and k == 1");
     hipLaunchKernelGGL((msda_sample_kernel<true, 0>), dim3((unsigned)R, 1), dim3(256), 0, stream, a);
@@ -421,6 +508,14 @@ int msda_sample(const MsdaArgs& a, hipStream_t stream) {
       if (a.k == 9) hipLaunchKernelGGL((msda_window_kernel<9, 9, LBM_MSDA_CAP, HPW>), wgrid, dim3(64 * HPW), 0, stream, b);
       else hipLaunchKernelGGL((msda_window_kernel<4, 9, LBM_MSDA_CAP, HPW>), wgrid, dim3(64 * HPW), 0, stream, b);
       return check_launch("msda_window");
+    }
+    if (use_taps) {
+      const long long rows = a.set_rows ? 2 * R : R;
+      LBM_REQUIRE(rows * LBM_HEADS <= 0x7fffffffLL, "msda_sample: too many rows");
+      const dim3 tgrid((unsigned)(rows * LBM_HEADS));
+      if (a.P == 9) hipLaunchKernelGGL((msda_taps_kernel<9, 1>), tgrid, dim3(64), 0, stream, b);
+      else hipLaunchKernelGGL((msda_taps_kernel<4, 1>), tgrid, dim3(64), 0, stream, b);
+      return check_launch("msda_taps");
     }
     if (a.P == 9) hipLaunchKernelGGL((msda_sample_kernel<false, 9>), grid, dim3(256), 0, stream, b);
     else if (a.P == 4) hipLaunchKernelGGL((msda_sample_kernel<false, 4>), grid, dim3(256), 0, stream, b);

@@ -19,13 +19,13 @@ def case(B, N, k, spread, off_scale=2.0, reps=5):
     offlog[:, :32 * 9] = (torch.rand(R, 32 * 9, generator=g) * 2 - 1) * off_scale
     offlog = offlog.cuda()
     centre = torch.rand(R, 1, 2, generator=g) * torch.tensor([512.0, 384.0])
-    side = 3 if k == 9 else 2
+    side = 3 if k == 9 else 2 if k == 4 else 1
     cells = torch.stack([torch.tensor([float(i % side), float(i // side)]) for i in range(k)], 0) * 4.0
     ref = ((centre // 4.0) * 4.0 + 2.0 + cells.unsqueeze(0)) if spread == "block" else torch.rand(R, k, 2, generator=g) * torch.tensor([512.0, 384.0])
     ref = ref.cuda().contiguous()
     res = {}
     outs = {}
-    for mode in (0, 1):
+    for mode in (0, 3):
         lib.lbm_hip_debug_set(22, mode)
         for _ in range(2):
             outs[mode] = hip.msda_sample(value, shapes, offlog, ref, B, N, k, 9, 512.0, 384.0)
@@ -37,9 +37,9 @@ def case(B, N, k, spread, off_scale=2.0, reps=5):
         e1.record()
         torch.cuda.synchronize()
         res[mode] = e0.elapsed_time(e1) / reps * 1e3
-    lib.lbm_hip_debug_set(22, 1)
-    same = torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))
-    print(f"B={B:3d} N={N:5d} k={k} {spread:9s} offsets +-{off_scale}: direct {res[0]:8.1f} us  window {res[1]:8.1f} us  x{res[0] / res[1]:.2f}  bit-identical={same}", flush=True)
+    lib.lbm_hip_debug_set(22, 3)
+    same = torch.equal(outs[0].view(torch.int32), outs[3].view(torch.int32))
+    print(f"B={B:3d} N={N:5d} k={k} {spread:9s} offsets +-{off_scale}: direct {res[0]:8.1f} us  window {res[3]:8.1f} us  x{res[0] / res[3]:.2f}  bit-identical={same}", flush=True)
 
 
 for B, N in ((64, 256), (1, 10000), (1, 1024)):
@@ -47,3 +47,5 @@ for B, N in ((64, 256), (1, 10000), (1, 1024)):
         for spread in ("block", "scattered"):
             case(B, N, k, spread)
 case(64, 256, 9, "block", off_scale=5.0)
+for B, N in ((64, 256), (1, 10000), (1, 1024)):
+    case(B, N, 1, "scattered")

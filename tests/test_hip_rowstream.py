@@ -295,6 +295,8 @@ def test_msda_xcd_aware_order_gives_the_same_rows(hip, B, N, k, P):
     (1, 33, 4, "mixed", 3.0, [(16, 24), (8, 12), (4, 6), (2, 3)]),              # tiny maps: the window is the whole coarse level
     (16, 9, 9, "mixed", 2.0, [(16, 24), (8, 12), (4, 6), (2, 3)]),              # a batch of streams: XCD-aware order of the point workgroups
     (1, 40, 9, "edge", 2.5, [(96, 128), (48, 64), (24, 32), (12, 16)]),         # reference cells on the map border: zero-padded taps
+    (1, 77, 1, "scattered", 2.0, [(96, 128), (48, 64), (24, 32), (12, 16)]),    # k = 1 (last layer, heads): the tap-table kernel
+    (8, 21, 1, "edge", 4.0, [(16, 24), (8, 12), (4, 6), (2, 3)]),               # k = 1, a batch of streams, borders
 ])
 def test_msda_window_kernel_gives_the_direct_kernels_rows(hip, B, N, k, spread, off_scale, shapes):
     """The LDS-staged form of msda_sample (k = 9 / 4 lattice launches: one workgroup per point, window of value cells staged per level
@@ -329,13 +331,50 @@ def test_msda_window_kernel_gives_the_direct_kernels_rows(hip, B, N, k, spread, 
     ref = ref.cuda().contiguous()
     outs = []
     try:
-        for mode in (0, 1):
+        for mode in (0, 3):
             lib.lbm_hip_debug_set(22, mode)
             hip.profile_begin()
             outs.append(hip.msda_sample(value, shapes, offlog, ref, B, N, k, P, net_w, net_h))
             names = {p["name"] for p in hip.profile_end()}
-            assert names == ({"msda_window"} if mode else {"msda_sample"}), names
+            assert names == (({"msda_taps"} if k == 1 else {"msda_window"}) if mode else {"msda_sample"}), names
     finally:
-        lib.lbm_hip_debug_set(22, 1)
+        lib.lbm_hip_debug_set(22, 3)
     assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))
     assert bool(torch.isfinite(outs[1]).all()) and float(outs[1].abs().max()) > 0
+
+
+def test_step_with_the_window_and_tap_table_kernels_equals_the_direct_gather(hip):
+    """Whole frames through LBM_online with every deformable sampling launch on the direct kernel (debug key 22 = 0) and on the
+    LDS-window / tap-table kernels (3, the default) -- k = 9, 4, 1, the paired offset + visibility heads (a two-module launch) and
+    the 4-point collision-memory head: tracks, logits and both memories bit for bit."""
+    from lbm_amd.config import LBMConfig
+    from lbm_amd.lbm_online import LBM_online
+    from lbm_amd.synth import random_queries, synthetic_state_dict, synthetic_video
+    lib = hip.load()
+    H, W, T = 120, 160, 5
+    video = synthetic_video(T, H, W, seed=5).cuda()
+    pts = random_queries(37, H, W, 9).cuda()
+    runs = []
+    try:
+        for mode in (0, 3):
+            lib.lbm_hip_debug_set(22, mode)
+            m = LBM_online(LBMConfig(input_size=(96, 128), memory_size=4).to_namespace())
+            m.load_state_dict(synthetic_state_dict(m, seed=42, preset="peaked"), strict=True)
+            m = m.cuda().eval()
+            got = []
+            with torch.no_grad():
+                m.init(pts, video[:, 0])
+                for t in range(1, T):
+                    if t == 2:
+                        hip.profile_begin()
+                    c, v, r, _ = m.online_forward(video[:, t])
+                    if t == 2:
+                        names = {p["name"] for p in hip.profile_end() if p["name"].startswith("msda")}
+                        assert names == ({"msda_window", "msda_taps"} if mode else {"msda_sample"}), names
+                    got += [c.clone(), m.last_logits[0].clone(), m.last_logits[1].clone()]
+                got += [m._stream.clone(), m._coll.clone()]
+            runs.append(got)
+    finally:
+        lib.lbm_hip_debug_set(22, 3)
+    for i, (x, y) in enumerate(zip(*runs)):
+        assert torch.equal(x.view(torch.int32), y.view(torch.int32)), f"entry {i}"

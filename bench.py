@@ -64,10 +64,13 @@ PRECISION_LABEL = {
     "split": "fp32 operands as split f16 hi/lo planes on the f16 matrix cores, fp32 accumulate (fp32-grade, passes the 1e-4 / 0.05 px parity bars)",
     "f32": "exact fp32 MFMA",
     "f16": "REDUCED precision: plain f16 operands on the matrix cores, fp32 accumulate (1e-2 logit bar); not the headline mode",
+    "f16s": "REDUCED precision, f16 STORAGE: both memories and the six value maps f16 in HBM, tracker products on plain f16 operands, but the "
+            "encoder and the correlation product + top-k fp32-grade (split) so the arg-max is decided on fp32-grade scores (1e-2 logit bar, "
+            "0.05 px); a secondary line, never the headline",
 }
 
 
-def build_model(wl, device, preset="flat"):
+def build_model(wl, device, preset="flat", precision=None):
     from lbm_amd.config import LBMConfig
     from lbm_amd.lbm_online import LBM_online
     from lbm_amd.synth import synthetic_state_dict
@@ -75,6 +78,8 @@ def build_model(wl, device, preset="flat"):
     model = LBM_online(cfg.to_namespace())
     sd = synthetic_state_dict(model, seed=42, preset=preset)
     model.load_state_dict(sd, strict=True)
+    if precision is not None:
+        model.set_precision(precision)
     model = model.to(device).eval()
     if wl["M"] != 12:
         model.set_memory_size(wl["M"])
@@ -172,9 +177,9 @@ def roofline_of(prof, steps_profiled):
 class Runner:
     """One workload on this rank's GPU: model, resident frames, the serial / pipelined frame loops and a state snapshot."""
 
-    def __init__(self, wl, rank, device, preset="flat"):
+    def __init__(self, wl, rank, device, preset="flat", precision=None):
         self.wl = wl
-        self.model, self.sd = build_model(wl, device, preset)
+        self.model, self.sd = build_model(wl, device, preset, precision)
         self.video_cpu, self.pts_cpu = make_inputs(wl, rank)
         video = self.video_cpu.to(device)                  # (B,T,3,H,W) resident in HBM
         self.pts = self.pts_cpu.to(device)
@@ -311,22 +316,12 @@ def measure_throughput(name, steps, warmup, rank, device, sync, profile=True, pr
     """One entry of `workloads`: the same Runner.time_loops as the headline (so `--workload c3` and `workloads.c3` are the same
     measurement up to the step count), plus the roofline entry of its dominant kernel."""
     w2 = WORKLOADS[name]
-    old = os.environ.get("LBM_AMD_PRECISION")
-    if precision is not None:
-        os.environ["LBM_AMD_PRECISION"] = precision
-    try:
-        r2 = Runner(w2, rank, device, preset)
-        e_s, e_p, same2, _ = r2.time_loops(steps, warmup, sync)
-        prof2 = r2.profile(4) if profile else []
-        roof2, kern2 = roofline_of(prof2, 4)
-        if roof2 is not None and precision is None:
-            attach_traffic(roof2, prof2, name)
-    finally:
-        if precision is not None:
-            if old is None:
-                os.environ.pop("LBM_AMD_PRECISION", None)
-            else:
-                os.environ["LBM_AMD_PRECISION"] = old
+    r2 = Runner(w2, rank, device, preset, precision)
+    e_s, e_p, same2, _ = r2.time_loops(steps, warmup, sync)
+    prof2 = r2.profile(4) if profile else []
+    roof2, kern2 = roofline_of(prof2, 4)
+    if roof2 is not None and precision is None:
+        attach_traffic(roof2, prof2, name)
     fl = step_flops(w2, r2.N, r2.B)
     ent = {"workload": w2["desc"], "weights": PRESET_LABEL[preset], "steps": steps, "ms_per_step": 1e3 * e_s / steps,
            "value": float(r2.B) * r2.N * steps / e_s, "unit": "point-frames/s",
@@ -500,6 +495,9 @@ def main():
                 # the deformable sampling the LDS window catches (and how often the fused top-k inserts)
                 other = "peaked" if args.preset == "flat" else "flat"
                 extra[f"{name}_{other}"] = measure_throughput(name, steps, 4, rank, device, local_sync, not args.no_profile, preset=other)
+                # the reduced-precision line (f16 storage; fp32-grade encoder and correlation + top-k): secondary, dtype stated per entry
+                extra[f"{name}_f16s"] = measure_throughput(name, steps, 4, rank, device, local_sync, not args.no_profile, precision="f16s",
+                                                           preset=args.preset)
             for name in ("c1", "c1_10"):
                 extra[name] = measure_clicks(name, rank, device, cpu=(name == "c1" and not args.no_cpu_baseline))
     headline_pipelined = el_pipe is not None and same and el_pipe < el_serial

@@ -24,7 +24,7 @@ extern "C" {
 
 typedef void* lbm_stream_t; /* hipStream_t */
 
-#define LBM_HIP_ABI_VERSION 4
+#define LBM_HIP_ABI_VERSION 5
 #define LBM_HIP_MAX_LAYERS 8
 
 int lbm_hip_version(void);
@@ -90,6 +90,11 @@ int lbm_hip_l2norm(const float* X, int64_t ldx, float* Y, int64_t ldy, int64_t r
 int lbm_hip_attn_readout(const float* U, const float* seq, int64_t point_stride, int64_t slot_stride,
                          int32_t S, int32_t ring_head, const float* temb, const uint8_t* mask_a,
                          const uint8_t* mask_b, float* out, uint8_t* valid, int32_t R, lbm_stream_t stream);
+/* The same read-out over an f16 sequence (strides in elements): the memories of the f16-storage mode (step precision 3).  The f16
+ * values are widened exactly, so the result equals lbm_hip_attn_readout on the widened sequence bit for bit.  temb is required. */
+int lbm_hip_attn_readout_h16(const float* U, const void* seq_f16, int64_t point_stride, int64_t slot_stride,
+                             int32_t S, int32_t ring_head, const float* temb, const uint8_t* mask_a,
+                             const uint8_t* mask_b, float* out, uint8_t* valid, int32_t R, lbm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * tokens[B, L, 256], level 0 in rows [0, h*w): fills levels 1..3 (avg-pool 2/4/8) in place.
@@ -130,6 +135,7 @@ typedef struct {
   const float* ref; float net_w, net_h;
   const float* loc; const float* attw;
   float* out;
+  int32_t value_f16;      /* 1: `value` points at f16 elements (same element strides), implicit mode only: the f16-storage mode's value maps */
 } lbm_hip_msda_desc;
 int lbm_hip_msda_sample(const lbm_hip_msda_desc* d, lbm_stream_t stream);
 
@@ -285,7 +291,12 @@ typedef struct {
    * precision 2: the reduced-precision mode ("bf16 storage with fp32 accumulate", bar 1e-2 on logits): the
    *   same kernels multiply the f16 hi planes only (plain f16 operands, 11 significant bits -- 3 more than bf16 --
    *   one MFMA per block, half the operand staging); weights_lo may be NULL.  Everything that is not a dense
-   *   contraction stays fp32.                                                                                     */
+   *   contraction stays fp32.
+   * precision 3: the f16-STORAGE mode, the reduced-precision mode to prefer (lbm_online.py:133-146 state; main.py:69 is the
+   *   reference's own fp16 practice): stream_mem / coll_mem point at F16 elements (same element layout, half the bytes), the six
+   *   projected value maps are f16 in the workspace, and every product of the step multiplies the hi planes only -- EXCEPT the
+   *   correlation product + top-k (transformer.py:306-313), which stay on both planes, so the arg-max is taken on fp32-grade
+   *   scores of the fp32-grade tokens (pass tokens / tokens_split from the fp32-grade encoder).  Bars: 1e-2 logits, 0.05 px.  */
   int32_t precision;
   const void* const* weights_lo;
   /* inputs */
@@ -293,7 +304,7 @@ typedef struct {
   const void* tokens_split;             /* optional (precision 1): split twin of tokens (lbm_hip_pyramid_s), lo plane
                                            B*L*256 elements after hi; NULL = the step derives it itself */
   const float* query;                   /* [B, N, 256] initial point tokens */
-  float* stream_mem;                    /* [B, N, M, 256] ring buffers */
+  float* stream_mem;                    /* [B, N, M, 256] ring buffers (precision 3: f16 elements behind these pointers) */
   float* coll_mem;
   uint8_t* vis_mask;                    /* [B, N, M] physical slot order */
   uint8_t* mem_mask;

@@ -101,7 +101,7 @@ static int build_layout(const lbm_hip_step_desc* d, StepLayout& lay) {
   LBM_REQUIRE(d != nullptr, "step: null descriptor");
   LBM_REQUIRE(d->B >= 1 && d->N >= 0 && d->M >= 1 && d->M <= 4096, "step: bad B/N/M (%d, %d, %d)", d->B, d->N, d->M);
   LBM_REQUIRE(d->n_layers >= 1 && d->n_layers <= LBM_HIP_MAX_LAYERS, "step: n_layers=%d out of range", d->n_layers);
-  LBM_REQUIRE(d->precision >= 0 && d->precision <= 2, "step: precision must be 0 (fp32 MFMA), 1 (split f16 MFMA) or 2 (plain f16 MFMA)");
+  LBM_REQUIRE(d->precision >= 0 && d->precision <= 3, "step: precision must be 0 (fp32 MFMA), 1 (split f16 MFMA), 2 (plain f16 MFMA) or 3 (f16 storage)");
   LBM_REQUIRE(d->stride == 4 && d->net_h % 32 == 0 && d->net_w % 32 == 0 && d->net_h > 0 && d->net_w > 0,
               "step: network input %dx%d (stride %d) must be a multiple of 32 with stride 4", d->net_h, d->net_w, d->stride);
   int kmax = 1;
@@ -118,7 +118,7 @@ static int build_layout(const lbm_hip_step_desc* d, StepLayout& lay) {
   lay.Q = lay.R * kmax;
   lay.n_vmaps = d->n_layers + 3;
   const unsigned long long f = sizeof(float);
-  lay.add("value", (unsigned long long)d->B * lay.L * lay.n_vmaps * LBM_C * f);
+  lay.add("value", (unsigned long long)d->B * lay.L * lay.n_vmaps * LBM_C * (d->precision == 3 ? 2 : f));      // (precision 3: f16 value maps)
   lay.add("inv_norm", (unsigned long long)d->B * lay.L * f);
   lay.add("corr_maps", (unsigned long long)d->n_layers * d->B * lay.P0 * LBM_C * f);
   lay.add("corr", (unsigned long long)lay.R * lay.P0 * f);
@@ -205,7 +205,9 @@ struct Step {
   char* ws;
   int h, w;
   bool split;      // precision 1 / 2: dense contractions on the f16 matrix cores with split operands
-  int planes = 2;  // 2: hi and lo planes multiplied (fp32-grade); 1: hi planes only (precision 2, reduced)
+  int planes = 2;  // 2: hi and lo planes multiplied (fp32-grade); 1: hi planes only (precision 2 / 3, reduced)
+  int cplanes = 2; // the same for the correlation product alone: precision 3 keeps it fp32-grade so the arg-max is the fp32 one
+  bool h16 = false; // precision 3: memories (caller's ring buffers) and the six value maps are f16 in HBM
   // Points never interact, so the per-point phase can run on any partition of the rows: this run covers
   // rows [lo, lo + R) of Rfull; `sub` of `nsub` names its private K-split slab region.
   long long Rfull = 0;
@@ -360,6 +362,7 @@ struct Step {
     if (U_pre == nullptr && linear(x_in, LBM_C, wb + LBM_W_ATTN_G, wb + LBM_W_ATTN_GB, U, 1024, R, 1024, LBM_C)) return -1;
     AttnArgs a;
     a.U = U_pre ? U_pre : U.f; a.ldu = U_pre ? ldu : 1024; a.seq = seq; a.point_stride = point_stride; a.slot_stride = LBM_C; a.S = S; a.ring_head = ring_head;
+    a.seq_f16 = (masked && h16) ? 1 : 0;         // the two memories; the lattice tokens of the update attention stay fp32
     a.temb = masked ? W(wb + LBM_W_ATTN_TEMB) : nullptr;
     a.mask_a = masked ? d->vis_mask + (long long)lo * d->M : nullptr;
     a.mask_b = masked ? d->mem_mask + (long long)lo * d->M : nullptr;
@@ -385,7 +388,8 @@ struct Step {
     const int ncol = 48 * P;
     if (ol_pre == nullptr && linear(x, LBM_C, wb + LBM_W_MSDA_OLW, wb + LBM_W_MSDA_OLB, offlog, ncol, R, ncol, LBM_C)) return -1;
     MsdaArgs m;
-    m.value = buf<float>("value") + (long long)vmap * LBM_C;
+    m.value = h16 ? reinterpret_cast<const float*>(buf<_Float16>("value") + (long long)vmap * LBM_C) : buf<float>("value") + (long long)vmap * LBM_C;
+    m.value_f16 = h16 ? 1 : 0;
     m.ldv = lay.n_vmaps * LBM_C;
     m.v_batch_stride = lay.L * m.ldv;
     int st = 0;
@@ -502,7 +506,9 @@ struct Step {
   // ---- per-frame, point-independent work: split tokens, the six value maps, the correlation maps ----
   int run_frame() {
     const int hb = d->n_layers * LBM_W_LAYER_COUNT;
-    TV value; value.f = buf<float>("value");
+    TV value;
+    if (h16) value.s = buf<char>("value");      // plain f16 rows (plane 0: no lo plane is written)
+    else value.f = buf<float>("value");
     const int nv = lay.n_vmaps * LBM_C;
     const long long BL = (long long)d->B * lay.L;
     TV tok; tok.f = const_cast<float*>(d->tokens);
@@ -543,8 +549,10 @@ struct Step {
     float* corr = buf<float>("corr") + (long long)lo * lay.P0;
     float* ref = buf<float>("ref") + (long long)lo * lay.kmax * 2;
     int* idx = buf<int>("idx") + (long long)lo * lay.kmax;
-    const float* coll_mem = d->coll_mem + (long long)lo * M * LBM_C;
-    const float* stream_mem = d->stream_mem + (long long)lo * M * LBM_C;
+    // (precision 3: the ring buffers hold f16 elements -- same element offsets, half the bytes)
+    const long long mem_off = (long long)lo * M * LBM_C;
+    const float* coll_mem = h16 ? reinterpret_cast<const float*>(reinterpret_cast<const _Float16*>(d->coll_mem) + mem_off) : d->coll_mem + mem_off;
+    const float* stream_mem = h16 ? reinterpret_cast<const float*>(reinterpret_cast<const _Float16*>(d->stream_mem) + mem_off) : d->stream_mem + mem_off;
     const bool one = nsub > 1;          // sub-run: one stream, M rows = R
     TV x = xq;
     for (int i = 0; i < d->n_layers; ++i) {
@@ -580,14 +588,14 @@ struct Step {
         // Row-streaming form (gemm_rs.hip): the MAP streams through LDS, 256 points at a time sit in registers, and every lane
         // keeps the k best cells of its point across all steps -- no scores leave the accumulators at all.
         int rs_cand = 0;
-        if (g_rs_topk && planes == 2 && d->corr[i] == nullptr && k <= 9) {
+        if (g_rs_topk && cplanes == 2 && d->corr[i] == nullptr && k <= 9) {
           rs_cand = gemm_rs_topk_cands((int)lay.P0, gm, gb, k);
           if (rs_cand < k || rs_cand > 4096 || rs_cand % 4 != 0 || 2ll * rs_cand > lay.P0) rs_cand = 0;
         }
-        fused_topk = rs_cand > 0 || (planes == 2 && d->corr[i] == nullptr && gemm_ss_topk_ok(gm, (int)lay.P0, LBM_C, gb, k) &&
+        fused_topk = rs_cand > 0 || (cplanes == 2 && d->corr[i] == nullptr && gemm_ss_topk_ok(gm, (int)lay.P0, LBM_C, gb, k) &&
                                      (k <= g_fuse_kmax_small || Rfull >= 4096));
         GemmSSArgs g;
-        g.planes = planes;
+        g.planes = cplanes;
         if (rs_cand > 0) {
           n_cand = rs_cand;
           g.cand_v = cdst;
@@ -670,7 +678,8 @@ struct Step {
     f.stream_out = d->stream_out ? d->stream_out + (long long)lo * LBM_C : nullptr;
     f.coll_out = d->coll_out ? d->coll_out + (long long)lo * LBM_C : nullptr;
     if (d->update_state) {
-      f.stream_mem = d->stream_mem + (long long)lo * M * LBM_C; f.coll_mem = d->coll_mem + (long long)lo * M * LBM_C;
+      f.stream_mem = const_cast<float*>(stream_mem); f.coll_mem = const_cast<float*>(coll_mem);
+      f.mem_f16 = h16 ? 1 : 0;
       f.vis_mask = d->vis_mask + (long long)lo * M; f.mem_mask = d->mem_mask + (long long)lo * M;
     }
     f.M = M; f.ring_head = d->ring_head; f.vis_threshold = d->vis_threshold;
@@ -746,6 +755,15 @@ int lbm_hip_attn_readout(const float* U, const float* seq, int64_t point_stride,
   return attn_readout(a, (hipStream_t)stream);
 }
 
+int lbm_hip_attn_readout_h16(const float* U, const void* seq_f16, int64_t point_stride, int64_t slot_stride, int32_t S,
+                             int32_t ring_head, const float* temb, const uint8_t* mask_a, const uint8_t* mask_b, float* out,
+                             uint8_t* valid, int32_t R, lbm_stream_t stream) {
+  AttnArgs a;
+  a.U = U; a.seq = (const float*)seq_f16; a.seq_f16 = 1; a.point_stride = point_stride; a.slot_stride = slot_stride; a.S = S; a.ring_head = ring_head;
+  a.temb = temb; a.mask_a = mask_a; a.mask_b = mask_b; a.out = out; a.valid = valid; a.R = R;
+  return attn_readout(a, (hipStream_t)stream);
+}
+
 int lbm_hip_pyramid(float* tokens, int32_t B, int32_t h, int32_t w, lbm_stream_t stream) {
   return pyramid_pool(tokens, B, h, w, (hipStream_t)stream);
 }
@@ -798,6 +816,7 @@ int lbm_hip_msda_sample(const lbm_hip_msda_desc* d, lbm_stream_t stream) {
   a.B = d->B; a.N = d->N; a.k = d->k; a.P = d->P;
   a.offlog = d->offlog; a.ld_offlog = d->ld_offlog; a.logit_col = d->logit_col;
   a.ref = d->ref; a.net_w = d->net_w; a.net_h = d->net_h; a.loc = d->loc; a.attw = d->attw; a.out = d->out;
+  a.value_f16 = d->value_f16 ? 1 : 0;
   return msda_sample(a, (hipStream_t)stream);
 }
 
@@ -1136,7 +1155,9 @@ int lbm_hip_track_step(const lbm_hip_step_desc* d, lbm_stream_t stream) {
     LBM_REQUIRE(d->vis && d->rho && d->offset, "step: vis/rho/offset outputs are required");
   }
   st.split = d->precision >= 1;
-  st.planes = d->precision == 2 ? 1 : 2;
+  st.planes = d->precision >= 2 ? 1 : 2;
+  st.cplanes = d->precision == 2 ? 1 : 2;
+  st.h16 = d->precision == 3;
   if (d->precision == 1) LBM_REQUIRE(d->weights_lo != nullptr, "step: precision 1 needs the lo planes of the weight matrices (weights_lo)");
   st.d = d;
   st.s = (hipStream_t)stream;

@@ -45,7 +45,7 @@ __device__ __forceinline__ float reduce16_lane(const float (&p)[16], int lane) {
 
 // XL: the group's exponentials evaluated across the lanes (see the loop); false = every lane evaluates all twenty (the first form,
 // kept for the bit-identity test: debug key 3, value + 16)
-template <int WPP, bool TEMB, bool XL = true>
+template <int WPP, bool TEMB, bool XL = true, typename ST = float>
 __global__ __launch_bounds__(256) void attn_readout_kernel(AttnArgs a) {
   __shared__ float sm_acc[WPP == 1 ? 1 : 4][LBM_HEADS][LBM_C];
   __shared__ float sm_ml[WPP == 1 ? 1 : 4][2][LBM_HEADS];
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void attn_readout_kernel(AttnArgs a) {
 #pragma unroll
   for (int hh = 0; hh < LBM_HEADS; ++hh) u[hh] = ld4(a.U + (long long)row * a.ldu + hh * LBM_C + lane * 4);
 
-  const float* sp = a.seq + (long long)row * a.point_stride + lane * 4;
+  const ST* sp = reinterpret_cast<const ST*>(a.seq) + (long long)row * a.point_stride + lane * 4;
   const uint8_t* ma = a.mask_a ? a.mask_a + (long long)row * a.S : nullptr;
   const uint8_t* mb = a.mask_b ? a.mask_b + (long long)row * a.S : nullptr;
 
@@ -251,7 +251,7 @@ int attn_readout(const AttnArgs& a, hipStream_t stream) {
               "attn_readout: strides must be multiples of 4 floats");
   // algorithmic traffic: the S sequence rows once, 4 per-head queries in, 4 per-head read-outs out, the masks
   ProfScope prof("attn_readout", stream, (double)a.R * a.S * 4.0 * LBM_C * 4,
-                 (double)a.R * (4.0 * LBM_C * (a.S + 8) + (a.mask_a ? a.S : 0) + (a.mask_b ? a.S : 0)));
+                 (double)a.R * (LBM_C * ((a.seq_f16 ? 2.0 : 4.0) * a.S + 4.0 * 8) + (a.mask_a ? a.S : 0) + (a.mask_b ? a.S : 0)));
   const int mode = g_attn_mode & 15;
   const bool wide = mode == 4 || (mode == 0 && a.R < 4096 && a.S >= 8);
   // two waves per point (forced with debug key 3 = 2 only): measured no faster than one at 10 000 points x 48 or 96 slots
@@ -259,7 +259,11 @@ int attn_readout(const AttnArgs& a, hipStream_t stream) {
   const bool pair = !wide && mode == 2 && !(g_attn_mode & 16);
   const dim3 grid(wide ? a.R : pair ? (a.R + 1) / 2 : (a.R + 3) / 4);
 #define LBM_ATTN_LAUNCH(W, T, X) hipLaunchKernelGGL((attn_readout_kernel<W, T, X>), grid, dim3(256), 0, stream, a)
-  if (g_attn_mode & 16) {      // the first form of the soft-max step (bit-identity test)
+  if (a.seq_f16) {             // f16 memories (f16-storage mode): the same kernel reading 512-byte slot rows
+    LBM_REQUIRE(a.temb != nullptr && !pair, "attn_readout: f16 sequences are the masked memory read-outs");
+    if (wide) hipLaunchKernelGGL((attn_readout_kernel<4, true, true, _Float16>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((attn_readout_kernel<1, true, true, _Float16>), grid, dim3(256), 0, stream, a);
+  } else if (g_attn_mode & 16) {      // the first form of the soft-max step (bit-identity test)
     if (wide) { if (a.temb) LBM_ATTN_LAUNCH(4, true, false); else LBM_ATTN_LAUNCH(4, false, false); }
     else { if (a.temb) LBM_ATTN_LAUNCH(1, true, false); else LBM_ATTN_LAUNCH(1, false, false); }
   } else {

@@ -20,6 +20,7 @@ struct AttnArgs {
   long long out_plane = 0;
   uint8_t* valid = nullptr;        // [R] 1 if at least one position was attended; may be null
   int R = 0;
+  int seq_f16 = 0;                 // 1: `seq` points at f16 elements (same element strides): the f16-storage mode's memories
 };
 
 int attn_readout(const AttnArgs& a, hipStream_t stream);

@@ -135,6 +135,25 @@ __device__ __forceinline__ void st4_split(void* hi_plane, long long plane, long 
 }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// the same four values from an f16 tensor (8 bytes; the f16-storage mode keeps memories and value maps that way)
+__device__ __forceinline__ float4 ld4(const _Float16* p) {
+  const half4 h = *reinterpret_cast<const half4*>(p);
+  return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+}
+// raw (unconverted) 4-element loads, for code that wants the conversion at the point of USE -- a conversion written next to the load
+// makes the compiler wait for the load right there, which defeats a prefetch
+__device__ __forceinline__ float4 ldraw4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ half4 ldraw4(const _Float16* p) { return *reinterpret_cast<const half4*>(p); }
+__device__ __forceinline__ float4 widen4(const float4 v) { return v; }
+__device__ __forceinline__ float4 widen4(const half4 h) { return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]); }
+__device__ __forceinline__ void st4h(_Float16* p, const float4 v) {      // round-to-nearest f16, magnitudes clamped like split1
+  half4 h;
+  h[0] = (_Float16)__builtin_amdgcn_fmed3f(v.x, -65000.f, 65000.f);
+  h[1] = (_Float16)__builtin_amdgcn_fmed3f(v.y, -65000.f, 65000.f);
+  h[2] = (_Float16)__builtin_amdgcn_fmed3f(v.z, -65000.f, 65000.f);
+  h[3] = (_Float16)__builtin_amdgcn_fmed3f(v.w, -65000.f, 65000.f);
+  *reinterpret_cast<half4*>(p) = h;
+}
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
 }  // namespace lbm

@@ -55,8 +55,13 @@ __global__ __launch_bounds__(256) void state_final_kernel(StateFinalArgs a) {
   if (a.coll_out) st4(a.coll_out + off, cv);
   if (a.stream_mem) {
     const long long so = ((long long)row * a.M + a.ring_head) * LBM_C + lane * 4;
-    st4(a.stream_mem + so, sv);
-    st4(a.coll_mem + so, cv);
+    if (a.mem_f16) {
+      st4h(reinterpret_cast<_Float16*>(a.stream_mem) + so, sv);
+      st4h(reinterpret_cast<_Float16*>(a.coll_mem) + so, cv);
+    } else {
+      st4(a.stream_mem + so, sv);
+      st4(a.coll_mem + so, cv);
+    }
   }
   if (lane == 0) {
     a.vis[row] = vis;

@@ -31,6 +31,7 @@ struct StateFinalArgs {
   float* rho_prob = nullptr;          // optional [R]: sigmoid(rho)
   float net_w = 0, net_h = 0, img_w = 0, img_h = 0;
   int R = 0;
+  int mem_f16 = 0;                    // 1: the ring buffers hold f16 elements (f16-storage mode)
 };
 
 int state_final(const StateFinalArgs& a, hipStream_t stream);

@@ -805,7 +805,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_ss_kernel(GemmSSDev a) {
       }
       if (a.act == ACT_RELU_POST) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
       if (Y) st4(Y + (long long)row * a.ldy + col, v);
-      if (Yh) st4_split(Yh, a.ys_plane, (long long)row * a.ldys + col, v);
+      if (Yh) {
+        if (a.ys_plane) st4_split(Yh, a.ys_plane, (long long)row * a.ldys + col, v);
+        else st4h(Yh + (long long)row * a.ldys + col, v);       // plain f16 output (hi plane only: f16-storage mode)
+      }
     }
     return;
   }
@@ -835,7 +838,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_ss_kernel(GemmSSDev a) {
             const float c = __builtin_amdgcn_fmed3f(v, -65000.f, 65000.f);
             const _Float16 hh = (_Float16)c;
             Yh[(long long)row * a.ldys + col] = hh;
-            Yl[(long long)row * a.ldys + col] = (_Float16)((c - (float)hh) * 2048.f);
+            if (a.ys_plane) Yl[(long long)row * a.ldys + col] = (_Float16)((c - (float)hh) * 2048.f);
           }
         }
       }

@@ -53,7 +53,7 @@ __device__ __forceinline__ Tap bilinear_tap(float lx, float ly, float w, int wl,
 // PT: compile-time number of points per level (0 = a.P at run time).  blockIdx.y selects the reference point: the k
 // lattice cells of a point are independent gathers, and one workgroup walking them in turn was bound by the latency of
 // its ~36 dependent-address loads per cell (106 us at 1024 points x 9 cells); the cheap stage 1 is simply repeated.
-template <bool EXPLICIT, int PT>
+template <bool EXPLICIT, int PT, typename VT = float>
 __global__ __launch_bounds__(256) void msda_sample_kernel(MsdaArgs a) {
   __shared__ float sm[LBM_HEADS][3][64];
   const int lane = threadIdx.x & 63;
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void msda_sample_kernel(MsdaArgs a) {
 
   // ---- stage 2: gather ----
   const int tap = lane >> 4, tx = tap & 1, ty = tap >> 1, cq = lane & 15;
-  const float* vb = a.value + (long long)b * a.v_batch_stride + set * a.set_value_off + hd * LBM_HD + cq * 4;
+  const VT* vb = reinterpret_cast<const VT*>(a.value) + (long long)b * a.v_batch_stride + set * a.set_value_off + hd * LBM_HD + cq * 4;
   {
     const int kk = kk_;
     float rx = 0.f, ry = 0.f;
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void msda_sample_kernel(MsdaArgs a) {
 //      kernel -- bit-identical rows -- reading a tap from the window, or straight from the value map when the learned offsets
 //      (unbounded) put it outside.
 // Waves never talk to each other: no workgroup barrier anywhere.
-template <int K, int PT, int CAP, int HPW>
+template <int K, int PT, int CAP, int HPW, typename VT = float>
 __global__ __launch_bounds__(64 * HPW) void msda_window_kernel(MsdaArgs a) {
   constexpr int NI = K * PT;                       // (reference cell, sample) pairs per level
   constexpr int NPASS = (NI + 63) / 64;
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(64 * HPW) void msda_window_kernel(MsdaArgs a) {
   const float4 rext = reinterpret_cast<const float4*>(ext)[4];              // rx lo, rx hi, ry lo, ry hi
 
   const int tap = lane >> 4, cq = lane & 15;
-  const float* vb = a.value + (long long)b * a.v_batch_stride + hd * LBM_HD + cq * 4;
+  const VT* vb = reinterpret_cast<const VT*>(a.value) + (long long)b * a.v_batch_stride + hd * LBM_HD + cq * 4;
   float4 acc[K];
 #pragma unroll
   for (int kk = 0; kk < K; ++kk) acc[kk] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(64 * HPW) void msda_window_kernel(MsdaArgs a) {
   // Branch-free on purpose -- under a per-lane `if` the compiler waits for each load in turn; slots outside WB x HB re-read the
   // window's last cell and are never referenced.  Issued one level AHEAD (registers), so their latency passes behind the tap
   // table and the accumulation of the level before.
-  float4 stg[NLD];
+  decltype(ldraw4(static_cast<const VT*>(nullptr))) stg[NLD];      // raw: f16 maps are widened when the window is written
   auto fetch = [&](int l, const Place& pl) {
     const int wl = a.lvl_w[l], st = a.lvl_start[l];
     if (pl.WB > 0 && !(LBM_ABL(a.dbg & 2))) {
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(64 * HPW) void msda_window_kernel(MsdaArgs a) {
         if ((it >> 1) < HBs && (it & 1) * 4 < WBs) {
           const int c = it * 4 + tap;
           const int cy = c >> 3, cx = min(c & 7, pl.WB - 1);
-          stg[it] = ld4(vb + (long long)(st + (pl.by0 + cy) * wl + pl.bx0 + cx) * a.ldv);
+          stg[it] = ldraw4(vb + (long long)(st + (pl.by0 + cy) * wl + pl.bx0 + cx) * a.ldv);
         }
       }
     }
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(64 * HPW) void msda_window_kernel(MsdaArgs a) {
     // 1. this level's window into LDS (fetched during the previous level), the next level's on its way
     if (pl.WB > 0 && !(LBM_ABL(a.dbg & 2))) {
 #pragma unroll
-      for (int it = 0; it < NLD; ++it) win[(it * 4 + tap) * 16 + cq] = stg[it];
+      for (int it = 0; it < NLD; ++it) win[(it * 4 + tap) * 16 + cq] = widen4(stg[it]);
     }
     if (l + 1 < LBM_LEVELS) {
       nxt = place(l + 1);
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(64 * HPW) void msda_window_kernel(MsdaArgs a) {
 // that kernel); here lane = sample does it once, parks (cell, weight) per tap in LDS, and the gather loop is a table read, a
 // load and four multiply-adds per sample.  Same expressions, same order of the sums: bit-identical rows.  One wave (= head) per
 // workgroup, or HPW of them; two-module launches (set_rows) as in the direct kernel.
-template <int PT, int HPW>
+template <int PT, int HPW, typename VT = float>
 __global__ __launch_bounds__(64 * HPW) void msda_taps_kernel(MsdaArgs a) {
   constexpr int S = LBM_LEVELS * PT;
   constexpr int WPP = LBM_HEADS / HPW;
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(64 * HPW) void msda_taps_kernel(MsdaArgs a) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   const int tap = lane >> 4, cq = lane & 15;
-  const float* vb = a.value + (long long)b * a.v_batch_stride + set * a.set_value_off + hd * LBM_HD + cq * 4;
+  const VT* vb = reinterpret_cast<const VT*>(a.value) + (long long)b * a.v_batch_stride + set * a.set_value_off + hd * LBM_HD + cq * 4;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 1
   for (int i0 = 0; i0 < S; i0 += PT) {
@@ -474,7 +474,7 @@ int msda_sample(const MsdaArgs& a, hipStream_t stream) {
   LBM_REQUIRE(a.value && (a.out || a.out_s), "msda_sample: null value/out");
   LBM_REQUIRE(a.P >= 1 && a.P <= 16, "msda_sample: P=%d must be in [1,16]", a.P);
   LBM_REQUIRE(a.k >= 1, "msda_sample: k=%d", a.k);
-  LBM_REQUIRE(a.ldv % 4 == 0 && a.v_batch_stride % 4 == 0 && ((uintptr_t)a.value & 15) == 0, "msda_sample: value must be 16-byte aligned");
+  LBM_REQUIRE(a.ldv % 4 == 0 && a.v_batch_stride % 4 == 0 && ((uintptr_t)a.value & (a.value_f16 ? 7 : 15)) == 0, "msda_sample: value rows must be 16-byte (f16: 8-byte) aligned");
   LBM_REQUIRE(R <= 0x7fffffffLL, "msda_sample: too many rows");
   long long tokens = 0;
   for (int l = 0; l < LBM_LEVELS; ++l) {
@@ -490,6 +490,7 @@ int msda_sample(const MsdaArgs& a, hipStream_t stream) {
   const bool use_taps = !explicit_mode && (g_msda_window & 2) && a.k == 1 && (a.P == 9 || a.P == 4);
   ProfScope prof(use_window ? "msda_window" : use_taps ? "msda_taps" : "msda_sample", stream, nq * 16.0 * a.P * 4 * 64 * 2, nq * (16.0 * a.P * 4 * 64 * 4 + 4.0 * LBM_C));
   if (explicit_mode) {
+    LBM_REQUIRE(!a.value_f16, "msda_sample: explicit mode reads fp32 value maps");
     LBM_REQUIRE(a.attw != nullptr && a.k == 1, "msda_sample: explicit mode needs attw and k == 1");
     hipLaunchKernelGGL((msda_sample_kernel<true, 0>), dim3((unsigned)R, 1), dim3(256), 0, stream, a);
   } else {
@@ -505,7 +506,10 @@ int msda_sample(const MsdaArgs& a, hipStream_t stream) {
       constexpr int HPW = LBM_MSDA_HPW;
       LBM_REQUIRE(R * (LBM_HEADS / HPW) <= 0x7fffffffLL, "msda_sample: too many rows");
       const dim3 wgrid((unsigned)(R * (LBM_HEADS / HPW)));
-      if (a.k == 9) hipLaunchKernelGGL((msda_window_kernel<9, 9, LBM_MSDA_CAP, HPW>), wgrid, dim3(64 * HPW), 0, stream, b);
+      if (a.value_f16) {
+        if (a.k == 9) hipLaunchKernelGGL((msda_window_kernel<9, 9, LBM_MSDA_CAP, HPW, _Float16>), wgrid, dim3(64 * HPW), 0, stream, b);
+        else hipLaunchKernelGGL((msda_window_kernel<4, 9, LBM_MSDA_CAP, HPW, _Float16>), wgrid, dim3(64 * HPW), 0, stream, b);
+      } else if (a.k == 9) hipLaunchKernelGGL((msda_window_kernel<9, 9, LBM_MSDA_CAP, HPW>), wgrid, dim3(64 * HPW), 0, stream, b);
       else hipLaunchKernelGGL((msda_window_kernel<4, 9, LBM_MSDA_CAP, HPW>), wgrid, dim3(64 * HPW), 0, stream, b);
       return check_launch("msda_window");
     }
@@ -513,11 +517,15 @@ int msda_sample(const MsdaArgs& a, hipStream_t stream) {
       const long long rows = a.set_rows ? 2 * R : R;
       LBM_REQUIRE(rows * LBM_HEADS <= 0x7fffffffLL, "msda_sample: too many rows");
       const dim3 tgrid((unsigned)(rows * LBM_HEADS));
-      if (a.P == 9) hipLaunchKernelGGL((msda_taps_kernel<9, 1>), tgrid, dim3(64), 0, stream, b);
+      if (a.value_f16) {
+        if (a.P == 9) hipLaunchKernelGGL((msda_taps_kernel<9, 1, _Float16>), tgrid, dim3(64), 0, stream, b);
+        else hipLaunchKernelGGL((msda_taps_kernel<4, 1, _Float16>), tgrid, dim3(64), 0, stream, b);
+      } else if (a.P == 9) hipLaunchKernelGGL((msda_taps_kernel<9, 1>), tgrid, dim3(64), 0, stream, b);
       else hipLaunchKernelGGL((msda_taps_kernel<4, 1>), tgrid, dim3(64), 0, stream, b);
       return check_launch("msda_taps");
     }
-    if (a.P == 9) hipLaunchKernelGGL((msda_sample_kernel<false, 9>), grid, dim3(256), 0, stream, b);
+    if (a.value_f16) hipLaunchKernelGGL((msda_sample_kernel<false, 0, _Float16>), grid, dim3(256), 0, stream, b);   // (a fallback only: the f16 mode's launches are window / tap-table shapes)
+    else if (a.P == 9) hipLaunchKernelGGL((msda_sample_kernel<false, 9>), grid, dim3(256), 0, stream, b);
     else if (a.P == 4) hipLaunchKernelGGL((msda_sample_kernel<false, 4>), grid, dim3(256), 0, stream, b);
     else hipLaunchKernelGGL((msda_sample_kernel<false, 0>), grid, dim3(256), 0, stream, b);
   }

@@ -31,6 +31,7 @@ struct MsdaArgs {
   // points and reference cells with another value map and another column block of offlog (element offsets below) ---
   int set_rows = 0;               // 0: one module
   long long set_value_off = 0, set_offlog_off = 0;
+  int value_f16 = 0;              // 1: `value` points at f16 elements (same element strides): the f16-storage mode's value maps
   int dbg = 0;                    // tuning build only (debug key 23): 1 no tap table, 2 no staging, 4 no accumulation, 8 no prologue reductions
   int xcd_streams = 0;            // set by msda_sample: workgroups dealt so that each XCD works through one stream's map at a time
 };

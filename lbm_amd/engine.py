@@ -55,7 +55,18 @@ def _pack_conv(w: torch.Tensor, cin_pad: int = 0) -> torch.Tensor:
 
 # "split": fp32 operands as f16 hi/lo planes, three MFMAs per block (fp32-grade, the default); "f32": exact fp32 MFMA;
 # "f16": hi planes only, one MFMA per block (the reduced-precision mode: 1e-2 on logits)
-PRECISIONS = ("split", "f32", "f16")
+# "f16s": the f16-STORAGE mode -- both memories and the six value maps are f16 in HBM and every product of the tracker except the
+#         correlation runs on the hi planes; the encoder and the correlation product + top-k stay fp32-grade (split), so the
+#         arg-max is decided on fp32-grade scores (step precision 3; 1e-2 on logits, 0.05 px on coordinates)
+PRECISIONS = ("split", "f32", "f16", "f16s")
+STEP_PRECISION = {"f32": 0, "split": 1, "f16": 2, "f16s": 3}
+
+
+def state_dtype(precision: Optional[str]) -> torch.dtype:
+    """dtype of the two ring-buffer memories for a tracker precision (None = LBM_AMD_PRECISION or "split")."""
+    import os
+    precision = precision or os.environ.get("LBM_AMD_PRECISION", "split")
+    return torch.float16 if precision == "f16s" else torch.float32
 
 
 class _Conv:
@@ -85,6 +96,8 @@ class EncoderWeights:
         precision = precision or os.environ.get("LBM_AMD_PRECISION", "split")
         if precision not in PRECISIONS:
             raise ValueError(f"precision must be one of {PRECISIONS}")
+        if precision == "f16s":          # the encoder stays fp32-grade in the f16-storage mode (the correlation reads its tokens)
+            precision = "split"
         self.precision = precision
         self.planes = 1 if precision == "f16" else 2
         dev = bb.frame_pos_embedding.device
@@ -413,8 +426,8 @@ class TrackEngine:
             d.corr_mix[i] = v
         for i, v in enumerate(self.w.corr_bias):
             d.corr_bias[i] = v
-        if self.precision in ("split", "f16"):
-            d.precision = 1 if self.precision == "split" else 2
+        if self.precision in ("split", "f16", "f16s"):
+            d.precision = STEP_PRECISION[self.precision]
             d.weights = C.cast(self.w.table_hi, C.POINTER(C.c_void_p))
             d.weights_lo = C.cast(self.w.table_lo, C.POINTER(C.c_void_p))
         else:
@@ -454,6 +467,9 @@ class TrackEngine:
                                f"{self.w.memory_size}; call set_memory_size first")
         B, N, M = stream_mem.shape[:3]
         cfg = self.cfg
+        mem_dt = state_dtype(self.precision)
+        if stream_mem.dtype != mem_dt or coll_mem.dtype != mem_dt:
+            raise hip.HipError(f"precision {self.precision!r} keeps the two memories as {mem_dt}, got {stream_mem.dtype} / {coll_mem.dtype}")
         d = self._desc(B, N, M)
         d.vis_threshold = vis_threshold
         d.ring_head, d.update_state = ring_head, 1 if update_state else 0
@@ -520,7 +536,7 @@ class TrackEngine:
                 out[f"corr{i}"] = torch.empty(B, N, P0, device=dev)
                 d.corr[i] = out[f"corr{i}"].data_ptr()
         d.tokens, d.query = hip._p(tokens), hip._p(query)
-        d.stream_mem, d.coll_mem = hip._p(stream_mem), hip._p(coll_mem)
+        d.stream_mem, d.coll_mem = hip._p(stream_mem, mem_dt), hip._p(coll_mem, mem_dt)
         d.vis_mask, d.mem_mask = hip._p(vis_mask, torch.uint8), hip._p(mem_mask, torch.uint8)
         d.queried = hip._p(queried, torch.uint8)
         d.coords, d.vis, d.rho, d.offset = (out[n].data_ptr() for n in ("coords", "vis", "rho", "offset"))

@@ -30,7 +30,7 @@ EXPORTS = (
     "lbm_hip_update_points", "lbm_hip_encoder_tail", "lbm_hip_pack_fragment_major", "lbm_hip_ffn_slabs",
     "lbm_hip_debug_ptr", "lbm_hip_update_points_static", "lbm_hip_preprocess_u8", "lbm_hip_corr_topk",
     "lbm_hip_corr_topk_workspace_bytes", "lbm_hip_preprocess_split", "lbm_hip_stem_pool",
-    "lbm_hip_encoder_tail_fused", "lbm_hip_debug_active", "lbm_hip_tuning_build",
+    "lbm_hip_encoder_tail_fused", "lbm_hip_debug_active", "lbm_hip_tuning_build", "lbm_hip_attn_readout_h16",
 )
 
 
@@ -64,7 +64,7 @@ class MsdaDesc(C.Structure):
                 ("B", C.c_int32), ("N", C.c_int32), ("k", C.c_int32), ("P", C.c_int32),
                 ("offlog", C.c_void_p), ("ld_offlog", C.c_int32), ("logit_col", C.c_int32),
                 ("ref", C.c_void_p), ("net_w", C.c_float), ("net_h", C.c_float),
-                ("loc", C.c_void_p), ("attw", C.c_void_p), ("out", C.c_void_p)]
+                ("loc", C.c_void_p), ("attw", C.c_void_p), ("out", C.c_void_p), ("value_f16", C.c_int32)]
 
 
 class StepDesc(C.Structure):
@@ -133,6 +133,7 @@ def load() -> C.CDLL:
     lib.lbm_hip_l2norm.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
     lib.lbm_hip_attn_readout.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    lib.lbm_hip_attn_readout_h16.argtypes = lib.lbm_hip_attn_readout.argtypes
     lib.lbm_hip_pyramid.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     lib.lbm_hip_corr_maps.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_int32, C.c_int32,
                                       C.c_int32, C.c_int32, C.c_void_p]
@@ -533,8 +534,10 @@ def attn_readout(U, seq, S, ring_head=0, temb=None, mask_a=None, mask_b=None, wa
     R = U.shape[0]
     out = torch.empty(R, 4, 256, device=U.device, dtype=torch.float32)
     valid = torch.empty(R, device=U.device, dtype=torch.uint8) if want_valid else None
-    _check(load().lbm_hip_attn_readout(_p(U), _p(seq), S * 256, 256, S, ring_head, _p(temb), _p(mask_a, torch.uint8),
-                                       _p(mask_b, torch.uint8), _p(out), _p(valid, torch.uint8), R, _stream()),
+    h16 = seq.dtype == torch.float16           # the f16-storage mode's memories
+    fn = load().lbm_hip_attn_readout_h16 if h16 else load().lbm_hip_attn_readout
+    _check(fn(_p(U), _p(seq, torch.float16 if h16 else torch.float32), S * 256, 256, S, ring_head, _p(temb), _p(mask_a, torch.uint8),
+              _p(mask_b, torch.uint8), _p(out), _p(valid, torch.uint8), R, _stream()),
            "lbm_hip_attn_readout")
     return (out, valid) if want_valid else out
 
@@ -603,7 +606,9 @@ def msda_sample(value: torch.Tensor, shapes, offlog: torch.Tensor, ref: torch.Te
     L = _fill_levels(d, shapes)
     ldv = value.shape[-1]
     out = torch.empty(B * N * k, 256, device=value.device, dtype=torch.float32)
-    d.value = _p(value) + vcol * 4
+    h16 = value.dtype == torch.float16         # the f16-storage mode's value maps
+    d.value = _p(value, value.dtype) + vcol * (2 if h16 else 4)
+    d.value_f16 = 1 if h16 else 0
     d.v_batch_stride, d.ldv = L * ldv, ldv
     d.B, d.N, d.k, d.P = B, N, k, P
     d.offlog, d.ld_offlog, d.logit_col = _p(offlog), offlog.shape[-1], 32 * P

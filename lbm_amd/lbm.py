@@ -46,7 +46,9 @@ class LBM(nn.Module):
 
     def set_precision(self, precision) -> None:
         """"split" (default): contractions on the f16 matrix cores with split operands, fp32-grade; "f32": exact fp32 MFMA;
-        "f16": reduced precision (plain f16 operands, fp32 accumulate; 1e-2 on logits), ~20 % faster."""
+        "f16": reduced precision (plain f16 operands, fp32 accumulate; 1e-2 on logits), ~20 % faster;
+        "f16s": f16 STORAGE of the memories and value maps, single-plane products, but an fp32-grade encoder and correlation +
+        top-k (the arg-max is the fp32-grade one): the reduced-precision mode to prefer."""
         self.backbone.set_precision(precision)
         self.transformer.set_precision(precision)
 
@@ -113,8 +115,10 @@ class LBM(nn.Module):
             if keep_tokens:
                 ts = self.backbone.last_tokens_split
                 cache[t] = (tok, None if ts is None else ts.clone())
-        stream = torch.zeros(B, N, M, self.embed_dim, device=dev)
-        coll = torch.zeros(B, N, M, self.embed_dim, device=dev)
+        from .engine import state_dtype
+        mem_dt = state_dtype(self.transformer.precision)
+        stream = torch.zeros(B, N, M, self.embed_dim, device=dev, dtype=mem_dt)
+        coll = torch.zeros(B, N, M, self.embed_dim, device=dev, dtype=mem_dt)
         vis_mask = torch.ones(B, N, M, device=dev, dtype=torch.uint8)
         mem_mask = torch.ones(B, N, M, device=dev, dtype=torch.uint8)
         pts, vis = [], []

@@ -84,11 +84,13 @@ class LBM_online(LBM):
 
     @property
     def stream_dist(self):
-        return self._logical(self._stream)
+        v = self._logical(self._stream)
+        return None if v is None else v.float()
 
     @property
     def collision_dist(self):
-        return self._logical(self._coll)
+        v = self._logical(self._coll)
+        return None if v is None else v.float()
 
     @property
     def vis_mask(self):
@@ -100,10 +102,15 @@ class LBM_online(LBM):
         v = self._logical(self._mem)
         return None if v is None else v.bool()
 
+    def _state_dtype(self) -> torch.dtype:
+        from .engine import state_dtype
+        return state_dtype(self.transformer.precision)
+
     def _alloc_state(self, B: int, N: int) -> None:
         dev, M, Cc = self.device, self.memory_size, self.embed_dim
-        self._stream = torch.zeros(B, N, M, Cc, device=dev)
-        self._coll = torch.zeros(B, N, M, Cc, device=dev)
+        dt = self._state_dtype()             # fp32, or f16 in the f16-storage mode (precision "f16s")
+        self._stream = torch.zeros(B, N, M, Cc, device=dev, dtype=dt)
+        self._coll = torch.zeros(B, N, M, Cc, device=dev, dtype=dt)
         self._vis = torch.ones(B, N, M, device=dev, dtype=torch.uint8)
         self._mem = torch.ones(B, N, M, device=dev, dtype=torch.uint8)
         self._head = 0
@@ -153,8 +160,13 @@ class LBM_online(LBM):
                 remove = None
                 self._head = 0
             # the ring head is untouched: kept rows move in their physical slot order
+            dt = self._state_dtype()
+            if old is not None and dt != torch.float32:      # f16-storage mode: the (rare) point-set edit goes through fp32 copies
+                old = (old[0], old[1].float(), old[2].float(), old[3], old[4])
             self.query, self._stream, self._coll, self._vis, self._mem = hip.update_points(
                 remove, update_mask.to(dev), old, new_q, self.memory_size)
+            if dt != torch.float32:
+                self._stream, self._coll = self._stream.to(dt), self._coll.to(dt)
             self.query_points = query_points
         self.N = N
         self.B = 1

@@ -143,7 +143,8 @@ class LBMTransformer(nn.Module):
         if tokens is None:
             tokens = self.tokens_from_feat(feat.float())
         eng = self.get_engine()
-        out = eng.step(tokens, query.contiguous().float(), stream_dist.contiguous().float(), collision_dist.contiguous().float(),
+        mem_dt = engine.state_dtype(self.precision)
+        out = eng.step(tokens, query.contiguous().float(), stream_dist.contiguous().to(mem_dt), collision_dist.contiguous().to(mem_dt),
                        vis_mask.contiguous(), mem_mask.contiguous(), ring_head=0,
                        queried=queried_now_or_before.contiguous(), update_state=False, want_memory=True, want_aux=True,
                        want_corr=self.return_corr)

@@ -8,7 +8,7 @@ from oracle import fixtures as fx, lbm_ref_cpu as ref
 
 g = fx.geometry("full256")
 inp = fx.step_inputs(g, 2, 300, seed=77)
-for prec in ("split", "f16"):
+for prec in ("split", "f16", "f16s"):
     tr, sd = T._transformer(g, precision=prec)
     with torch.no_grad():
         want = ref.transformer_forward(sd, g, inp["query"], inp["feat"], inp["stream"], inp["collision"], inp["vis_mask"],

@@ -11,10 +11,15 @@ shapes = [(96, 128), (48, 64), (24, 32), (12, 16)]
 L = sum(h * w for h, w in shapes)
 
 
+H16 = len(sys.argv) > 1 and sys.argv[1] == "f16"       # value maps stored as f16 (the f16-storage mode)
+
+
 def case(B, N, k, spread, off_scale=2.0, reps=5):
     g = torch.Generator(device="cpu").manual_seed(1)
     R = B * N
     value = torch.randn(B, L, 256, generator=g).cuda()
+    if H16:
+        value = value.half()
     offlog = torch.randn(R, 48 * 9, generator=g)
     offlog[:, :32 * 9] = (torch.rand(R, 32 * 9, generator=g) * 2 - 1) * off_scale
     offlog = offlog.cuda()

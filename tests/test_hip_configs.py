@@ -24,26 +24,34 @@ pytestmark = pytest.mark.gpu
 
 COORD_TOL, LOGIT_TOL, TIE = 0.05, 1e-3, 1e-4
 ALLOW = {"flat": 0.02, "peaked": 0.01}          # share of the compared points the tie rule may remove, per checkpoint preset
+# The f16-storage mode (precision "f16s": memories and value maps f16 in HBM, single-plane products, fp32-grade encoder and
+# correlation + top-k): the north star's reduced-precision bars -- 0.05 px, 1e-2 on the logits -- for EVERY point whose selections
+# were not ties.  Its operands carry 11 bits, so what reaches the (exact) correlation product from the layers before differs from
+# the oracle by ~1e-4 of a score: "tie" means an oracle k / (k+1) gap below 1e-3 here, ten times the fp32 rule (the logit bar is a
+# hundred times looser).
+F16S = dict(coord=0.05, logit=1e-2, tie=1e-3, allow={"flat": 0.10, "peaked": 0.01})
 
 
 def _report(tag, streams):
     import os
     n = sum(len(o.dropped) for o in streams)
     line = (f"{tag}: {sum(int(o.dropped.sum()) for o in streams)} of {n} compared points dropped by the tie rule "
-            f"({sum(int(o.tie_seen.sum()) for o in streams)} had an oracle k/(k+1) gap < {TIE:g} at some layer and frame)")
+            f"({sum(int(o.tie_seen.sum()) for o in streams)} had an oracle k/(k+1) gap < {streams[0].tie:g} at some layer and frame)")
     print(line)
     if os.path.isdir("gpurun_out"):
         with open("gpurun_out/parity_drops.txt", "a") as f:
             f.write(line + "\n")
 
 
-def _model(M, preset="flat"):
+def _model(M, preset="flat", precision=None):
     from lbm_amd.config import LBMConfig
     from lbm_amd.lbm_online import LBM_online
     from lbm_amd.synth import synthetic_state_dict
     model = LBM_online(LBMConfig(input_size=(384, 512), memory_size=12).to_namespace())
     sd = synthetic_state_dict(model, seed=42, preset=preset)
     model.load_state_dict(sd, strict=True)
+    if precision is not None:
+        model.set_precision(precision)
     model = model.cuda().eval()
     g = ref.Geometry(size=(384, 512), memory_size=12)
     sd = {k: v.clone() for k, v in sd.items()}
@@ -56,8 +64,8 @@ def _model(M, preset="flat"):
 class _OracleStream:
     """RefOnline (lbm_online.py:27-158 restated) plus the book-keeping of the tie rule in the header."""
 
-    def __init__(self, sd, g, pts, first_frame, allow=ALLOW["flat"]):
-        self.allow = allow
+    def __init__(self, sd, g, pts, first_frame, allow=ALLOW["flat"], coord=COORD_TOL, logit=LOGIT_TOL, tie=TIE):
+        self.allow, self.coord, self.logit, self.tie = allow, coord, logit, tie
         self.o = ref.RefOnline(sd, g)
         self.o.init(pts, first_frame)
         self.tie_seen = torch.zeros(pts.shape[0], dtype=torch.bool)
@@ -70,7 +78,7 @@ class _OracleStream:
         coords, vis, rho, out = ref.track_step(o.sd, g, o.state, feat)
         for layer, k in zip(out, g.topk_per_layer):
             tv = torch.topk(layer["corr"][0], k + 1, dim=-1)[0]
-            self.tie_seen |= (tv[:, k - 1] - tv[:, k]) < TIE
+            self.tie_seen |= (tv[:, k - 1] - tv[:, k]) < self.tie
         c = coords[0].clone()
         c[:, 0] = c[:, 0] / g.size[1] * W
         c[:, 1] = c[:, 1] / g.size[0] * H
@@ -78,8 +86,8 @@ class _OracleStream:
 
     def check(self, tag, got_c, got_vis, got_rho, want):
         c, vl, rl = want
-        off = ((got_c.cpu() - c).abs().amax(-1) >= COORD_TOL) | ((got_vis.cpu() - vl).abs() >= LOGIT_TOL) | \
-              ((got_rho.cpu() - rl).abs() >= LOGIT_TOL)
+        off = ((got_c.cpu() - c).abs().amax(-1) >= self.coord) | ((got_vis.cpu() - vl).abs() >= self.logit) | \
+              ((got_rho.cpu() - rl).abs() >= self.logit)
         unexplained = off & ~self.tie_seen & ~self.dropped
         assert not bool(unexplained.any()), (f"{tag}: points {torch.nonzero(unexplained).flatten().tolist()[:8]} differ from the oracle "
                                              f"(coords by up to {float((got_c.cpu() - c).abs().amax(-1)[unexplained].max()):.3f} px) "
@@ -167,6 +175,56 @@ def test_c5_1080p_dense_grid_long_memory_against_the_oracle_on_sampled_points(pr
         _check_state = (model.stream_dist[0, sel.cuda()].cpu() - o.o.state.stream[0]).abs().amax((-1, -2))
         assert _check_state[o.stable].max() < 5e-3
         assert (model.vis_mask[0, sel.cuda()].cpu() == o.o.state.vis_mask[0])[o.stable].float().mean() > 0.999
+
+
+@pytest.mark.parametrize("preset", ["peaked", "flat"])
+def test_f16_storage_mode_at_c3_and_c5_sizes(preset):
+    """Precision "f16s" on BASELINE configs 3 and 5 against the fp32 CPU oracle: every point whose selections were not ties within
+    0.05 px and 1e-2 on both logits (bars and tie rule in the header).  C3: streams 0 and 63 of 64 x 256 points, 3 frames; C5: 48
+    sampled points of the 10 000, memory 48, 8 frames.  Memories must really be f16."""
+    from lbm_amd.synth import grid_queries, random_queries, synthetic_video
+    bars = dict(allow=F16S["allow"][preset], coord=F16S["coord"], logit=F16S["logit"], tie=F16S["tie"])
+    # ---- C3
+    B, N, T, H, W = 64, 256, 4, 480, 854
+    base = synthetic_video(T, H, W, seed=42)[0]
+    video = torch.stack([torch.roll(base, shifts=(3 * s) % W, dims=-1) if s else base for s in range(B)], 0)
+    pts = torch.stack([random_queries(N, H, W, 42 + s) for s in range(B)], 0)
+    model, sd, g = _model(12, preset, "f16s")
+    vid = video.cuda()
+    with torch.no_grad():
+        model.init_streams(pts.cuda(), vid[:, 0].contiguous())
+        assert model._stream.dtype == torch.float16 and model._coll.dtype == torch.float16
+        got = []
+        for t in range(1, T):
+            c, v, r, _ = model.online_forward_batch(vid[:, t].contiguous())
+            got.append((c.clone(), model.last_logits[0].clone(), model.last_logits[1].clone()))
+        oracles = []
+        for s in (0, 63):
+            o = _OracleStream(sd, g, pts[s], video[s, :1], **bars)
+            oracles.append(o)
+            for t in range(1, T):
+                o.check(f"f16s c3 {preset} stream {s} frame {t}", got[t - 1][0][s], got[t - 1][1][s], got[t - 1][2][s], o.step(video[s, t:t + 1]))
+        _report(f"c3 f16s {preset}", oracles)
+        assert model.stream_dist.dtype == torch.float32          # the reference-layout view widens
+    del model, vid, video
+    torch.cuda.empty_cache()
+    # ---- C5
+    M, H, W, NF, T = 48, 1080, 1920, 4, 8
+    video = synthetic_video(NF + 1, H, W, seed=42)
+    pts = grid_queries(H, W, 100)
+    sel = torch.linspace(0, pts.shape[0] - 1, 48).long()
+    model, sd, g = _model(M, preset, "f16s")
+    vid = video.cuda()
+    with torch.no_grad():
+        model.init(pts.cuda(), vid[:, 0].contiguous())
+        o = _OracleStream(sd, g, pts[sel], video[:, 0], **bars)
+        for t in range(T):
+            f = 1 + t % NF
+            c, v, r, _ = model.online_forward(vid[:, f].contiguous())
+            o.check(f"f16s c5 {preset} frame {t}", c[sel.cuda()], model.last_logits[0][0][sel.cuda()], model.last_logits[1][0][sel.cuda()],
+                    o.step(video[:, f]))
+        _report(f"c5 f16s {preset}", [o])
+        assert model._stream.dtype == torch.float16
 
 
 def test_split_operand_clamp_is_pinned():

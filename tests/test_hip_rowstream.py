@@ -378,3 +378,41 @@ def test_step_with_the_window_and_tap_table_kernels_equals_the_direct_gather(hip
         lib.lbm_hip_debug_set(22, 3)
     for i, (x, y) in enumerate(zip(*runs)):
         assert torch.equal(x.view(torch.int32), y.view(torch.int32)), f"entry {i}"
+
+
+# ---- f16-storage mode (step precision 3): operators on f16 data equal the fp32 operators on the widened data, bit for bit ----
+
+def test_f16_value_maps_give_the_rows_of_the_widened_maps(hip):
+    """msda_window / msda_taps reading f16 value maps (the f16-storage mode) against the fp32 kernels on the same values widened to fp32:
+    the widening is exact and the arithmetic identical, so every row must match bit for bit."""
+    g = torch.Generator(device="cpu").manual_seed(77)
+    shapes = [(96, 128), (48, 64), (24, 32), (12, 16)]
+    L = sum(h * w for h, w in shapes)
+    for B, N, k in ((1, 50, 9), (8, 12, 4), (1, 90, 1)):
+        v16 = torch.randn(B, L, 512, generator=g).cuda().half()              # a 512-wide interleaved map: columns 256..511 are used
+        offlog = torch.randn(B * N, 48 * 9, generator=g)
+        offlog[:, :32 * 9] *= 2.5
+        centre = torch.rand(B * N, 1, 2, generator=g) * torch.tensor([512.0, 384.0])
+        side = 3 if k == 9 else 2 if k == 4 else 1
+        cells = torch.stack([torch.tensor([float(i % side), float(i // side)]) for i in range(k)], 0) * 4.0
+        ref = ((centre // 4.0) * 4.0 + 2.0 + cells.unsqueeze(0)).cuda().contiguous()
+        a = hip.msda_sample(v16, shapes, offlog.cuda(), ref, B, N, k, 9, 512.0, 384.0, vcol=256)
+        b = hip.msda_sample(v16.float(), shapes, offlog.cuda(), ref, B, N, k, 9, 512.0, 384.0, vcol=256)
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (B, N, k)
+        assert float(a.abs().max()) > 0
+
+
+@pytest.mark.parametrize("R,S,head", [(40, 12, 5), (3000, 48, 17), (9, 70, 0)])
+def test_f16_memories_read_out_like_the_widened_memories(hip, R, S, head):
+    """lbm_hip_attn_readout_h16 (memories stored as f16) against lbm_hip_attn_readout on the widened sequence: bit for bit, both
+    wave mappings, masks and ring order included."""
+    g = torch.Generator(device="cpu").manual_seed(R + S)
+    U = (torch.randn(R, 4, 256, generator=g) * 0.15).cuda()
+    seq = torch.randn(R, S, 256, generator=g).cuda().half()
+    temb = (torch.randn(S, 256, generator=g) * 0.5).cuda()
+    ma = (torch.rand(R, S, generator=g) < 0.3).cuda().to(torch.uint8)
+    mb = (torch.rand(R, S, generator=g) < 0.2).cuda().to(torch.uint8)
+    ma[0] = 1
+    a, va = hip.attn_readout(U, seq, S, ring_head=head, temb=temb, mask_a=ma, mask_b=mb, want_valid=True)
+    b, vb = hip.attn_readout(U, seq.float(), S, ring_head=head, temb=temb, mask_a=ma, mask_b=mb, want_valid=True)
+    assert torch.equal(a.view(torch.int32), b.view(torch.int32)) and torch.equal(va, vb)

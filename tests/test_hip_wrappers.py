@@ -322,3 +322,43 @@ def test_inference_at_the_eval_memory_sizes_against_the_oracle(M):
             with open("gpurun_out/parity_drops.txt", "a") as f:
                 f.write(line + "\n")
         assert dropped.float().mean() <= 0.05, f"M {M}: {int(dropped.sum())} of {N} points lost to ties"
+
+
+def test_f16_storage_mode_through_update_and_inference(gold):
+    """Precision "f16s" (memories + value maps f16 in HBM) through the parts of the API that touch the state: update() (add / drop /
+    re-plant points: the edit goes through fp32 copies and comes back as f16) and LBM.inference (late queries).  Against the
+    fp32-grade run of the same model: same tracks within the reduced-precision bars for the points both runs kept on the same cells."""
+    g, inp = gold
+    video = inp["video"].cuda()
+    runs = {}
+    for prec in ("split", "f16s"):
+        o = _model("LBM_online")
+        o.set_precision(prec)
+        o = o.cuda()
+        out = []
+        with torch.no_grad():
+            o.init(inp["pts0"].cuda(), video[:, 0])
+            for t in range(1, 4):
+                c, v, r, f_t = o.online_forward(video[:, t])
+                out.append((c.clone(), o.last_logits[0][0].clone()))
+            o.update(inp["pts1"].cuda(), f_t, inp["update"].cuda(), inp["remove"].cuda())
+            assert o.N == 11 and o._stream.dtype == (torch.float16 if prec == "f16s" else torch.float32)
+            assert o.stream_dist.dtype == torch.float32
+            for t in range(4, 7):
+                c, v, r, f_t = o.online_forward(video[:, t])
+                out.append((c.clone(), o.last_logits[0][0].clone()))
+        runs[prec] = out
+    close = total = 0
+    for (ca, la), (cb, lb) in zip(runs["split"], runs["f16s"]):
+        same = (ca - cb).abs().amax(-1) < 0.05
+        close += int(same.sum()); total += same.numel()
+        assert float((la - lb).abs()[same].max()) < 1e-2
+    assert close / total > 0.9, f"only {close} of {total} point-frames agree between the f16-storage and the fp32-grade run"
+    m = _model("LBM")
+    m.set_precision("f16s")
+    m = m.cuda()
+    m.extend_queries = False
+    with torch.no_grad():
+        res = m.inference(inp["video"][:, :6].cuda(), inp["queries"].clone().cuda())
+    d = np.abs(res["points"].cpu().numpy() - g["inf_points"]).max(-1)
+    assert (d < 0.05).mean() > 0.9 and np.isfinite(d).all()

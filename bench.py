@@ -152,7 +152,7 @@ def roofline_of(prof, steps_profiled):
         f32 = dom["name"].startswith(("gemm_f32", "conv_f32"))
         peak = F32_MFMA_PEAK_TF if f32 else F16_MFMA_PEAK_TF
         roof = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
-                "mfma_flops_per_algorithmic_flop": 1 if (f32 or dom["name"].startswith(("gemm_sh", "conv_sh", "ffn_fused_sh"))) else 3}
+                "mfma_flops_per_algorithmic_flop": 1 if (f32 or dom["name"].startswith(("gemm_sh", "gemm_rh", "conv_sh", "ffn_fused_sh"))) else 3}
     elif dom["name"].startswith(("msda_sample", "msda_window")):
         # a gather out of a 16.7 MB map that every workgroup shares: served by the L2s, not by HBM -- priced against the
         # guide's L2 shared-row rate, reported under bound "hbm" would exceed 1

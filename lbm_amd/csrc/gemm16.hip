@@ -1062,7 +1062,7 @@ int gemm_ss(const GemmSSArgs& a, hipStream_t stream) {
   int t = g_force_tile16;
   // K = 256 and many rows: the row-streaming kernel (weights stationary in registers), gemm_rs.hip.  Debug flags: 256 = never,
   // 512 = whenever the shape admits it.
-  if (t == 0 && !(g_dbg16 & 256) && a.planes == 2 && gemm_rs_ok(a) && ((g_dbg16 & 512) || a.M >= g_rs_min_rows))
+  if (t == 0 && !(g_dbg16 & 256) && gemm_rs_ok(a) && ((g_dbg16 & 512) || a.M >= g_rs_min_rows))
     return gemm_rs(a, (g_dbg16 >> 12) & 0xffff, stream);
   const long long mid = (long long)((a.M + 63) / 64) * ((a.N + 63) / 64) * a.batch;
   LBM_REQUIRE(a.planes == 1 || a.planes == 2, "gemm_ss: planes must be 1 or 2");

@@ -56,8 +56,10 @@ typedef __attribute__((address_space(3))) void* lds_ptr_rs;
 
 template <int N>
 __device__ __forceinline__ void wait_vm() {
-  static_assert(N == 0 || N == 4 || N == 8 || N == 12 || N == 16, "unsupported vmcnt");
+  static_assert(N == 0 || N == 2 || N == 4 || N == 6 || N == 8 || N == 12 || N == 16, "unsupported vmcnt");
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
@@ -81,8 +83,12 @@ __device__ __forceinline__ void st8_asm(_Float16* p, const half4 d, const bool n
 // RES: the linear epilogue adds a residual (the only ordinary loads inside the loop: beside them the compiler drains the DMA queue)
 // NST: output store instructions a wave issues per step (4 per fp32 output, 8 per split output): lets the step loop's counted wait
 // leave the previous epilogue's stores in flight (gfx9 retires the VM counter in issue order)
-template <int EPI, int KM, bool RES = false, int NST = 0>
+// NPL: operand planes multiplied.  2 = split operands, three MFMAs per block (fp32-grade); 1 = the hi planes only (plain f16
+// operands: the f16-storage mode's value projection) -- the lo planes are neither fetched nor multiplied (EPI 0 only)
+template <int EPI, int KM, bool RES = false, int NST = 0, int NPL = 2>
 __global__ __launch_bounds__(512) void gemm_rs_kernel(GemmRSDev a) {
+  static_assert(NPL == 2 || EPI == 0, "single-plane form: linear epilogue only");
+  constexpr int NP = 2 * NPL;                         // LDS-DMA pieces a wave issues per step
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int STAGE = 32768, NS = 3, TP = 36;
   constexpr int LDS_BYTES = NS * STAGE + (EPI == 0 ? 8 * 32 * TP * 4 : 0);
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(512) void gemm_rs_kernel(GemmRSDev a) {
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
       fbh[ks] = *reinterpret_cast<const half8*>(tp + ks * 16);
-      fbl[ks] = *reinterpret_cast<const half8*>(tp + a.t_plane + ks * 16);
+      if constexpr (NPL == 2) fbl[ks] = *reinterpret_cast<const half8*>(tp + a.t_plane + ks * 16);
     }
   }
 
@@ -144,7 +150,7 @@ __global__ __launch_bounds__(512) void gemm_rs_kernel(GemmRSDev a) {
   auto issue = [&](int stage, int step) {
     const int mb = (s0 + step) * 32;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NP; ++i) {
       const int pl = i >> 1, half = i & 1;
       const int row = half * 16 + drow;
       const int slot = (lane & 3) ^ ((row >> 2) & 3);
@@ -184,9 +190,9 @@ __global__ __launch_bounds__(512) void gemm_rs_kernel(GemmRSDev a) {
   auto ldg = [&](const unsigned char* Ab, const int bsel, const int g) __attribute__((always_inline)) {
     const unsigned char* p = Ab + g * 4096;
     fa[bsel][0] = *reinterpret_cast<const half8*>(p + o0);
-    fa[bsel][1] = *reinterpret_cast<const half8*>(p + 2048 + o0);
+    if constexpr (NPL == 2) fa[bsel][1] = *reinterpret_cast<const half8*>(p + 2048 + o0);
     fa[bsel][2] = *reinterpret_cast<const half8*>(p + o1);
-    fa[bsel][3] = *reinterpret_cast<const half8*>(p + 2048 + o1);
+    if constexpr (NPL == 2) fa[bsel][3] = *reinterpret_cast<const half8*>(p + 2048 + o1);
   };
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   auto grp = [&](const int g) __attribute__((always_inline)) {
@@ -195,7 +201,8 @@ __global__ __launch_bounds__(512) void gemm_rs_kernel(GemmRSDev a) {
       const int ks = 2 * g + q;
       const bool first = g == 0 && q == 0;
       acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[g & 1][2 * q], fbh[ks], first ? zero16 : acc, 0, 0, 0);
-      if constexpr (EPI == 0) {       // (activations hi x weights lo) then (activations lo x weights hi): the tiled kernel's order
+      if constexpr (NPL == 1) {
+      } else if constexpr (EPI == 0) {       // (activations hi x weights lo) then (activations lo x weights hi): the tiled kernel's order
         acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[g & 1][2 * q], fbl[ks], first ? zero16 : acx, 0, 0, 0);
         acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[g & 1][2 * q + 1], fbh[ks], acx, 0, 0, 0);
       } else {                        // roles swapped (S = map, T = points): (points hi x map lo) then (points lo x map hi), as there
@@ -278,7 +285,7 @@ __global__ __launch_bounds__(512) void gemm_rs_kernel(GemmRSDev a) {
             split4(v, sh, sl);
             _Float16* yp = Yh + (long long)srow * a.ldys + col;
             st8_asm(yp, sh, nt);
-            st8_asm(yp + a.ys_plane, sl, nt);
+            if (a.ys_plane) st8_asm(yp + a.ys_plane, sl, nt);       // (ys_plane 0: plain f16 output, the hi plane alone)
           }
         }
       }
@@ -316,10 +323,10 @@ __global__ __launch_bounds__(512) void gemm_rs_kernel(GemmRSDev a) {
     // without columns issue no stores; with a residual the compiler's own waits for the residual loads drain the queue anyway.
     const bool more = s + 1 < ns;
     if (s >= 2 && active && !RES && NST > 0 && !(LBM_ABL(a.dbg & 128))) {
-      if (more) wait_vm<NST + 4>();
+      if (more) wait_vm<NST + NP>();
       else wait_vm<NST>();
     } else {
-      if (more) wait_vm<4>();
+      if (more) wait_vm<NP>();
       else wait_vm<0>();
     }
     if (!(LBM_ABL(a.dbg & 2048))) __builtin_amdgcn_s_barrier();          // every wave's pieces of step s are in; every wave is done reading step s - 1
@@ -338,7 +345,7 @@ __global__ __launch_bounds__(512) void gemm_rs_kernel(GemmRSDev a) {
     if (mm) half_step(Ab, 4);
     if (active) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) out[e] = (acc[e] + acx[e] * (1.0f / 2048.0f)) + bv;
+      for (int e = 0; e < 16; ++e) out[e] = (NPL == 2 ? acc[e] + acx[e] * (1.0f / 2048.0f) : acc[e]) + bv;
     }
   }
   if (active) epi(ns - 1);
@@ -383,9 +390,12 @@ static long long rs_grid(const GemmRSDev& d) {
 
 bool gemm_rs_ok(const GemmSSArgs& a) {
   auto al = [](const void* p, uintptr_t m) { return ((uintptr_t)p & (m - 1)) == 0; };
-  if (a.planes != 2 || a.K != 256 || a.topk_k != 0 || a.N % 4 != 0 || a.M < 1) return false;
+  if (a.K != 256 || a.topk_k != 0 || a.N % 4 != 0 || a.M < 1) return false;
+  // hi planes only: the one shape the f16-storage mode needs -- plain f16 output, no fp32 copy, no residual
+  if (a.planes != 2 && !(a.planes == 1 && a.Ys && a.ys_plane == 0 && !a.Y && !a.res)) return false;
   if (a.Y && !(a.ldy % 4 == 0 && a.sY % 4 == 0 && al(a.Y, 16))) return false;
   if (a.Ys && !(a.ldys % 4 == 0 && a.sYs % 4 == 0 && a.ys_plane % 4 == 0 && al(a.Ys, 8))) return false;
+  if (a.Ys && a.ys_plane == 0 && a.Y) return false;       // plain f16 output: the store count per step (4) assumes it is the only output
   if (a.res && !(a.ldres % 4 == 0 && a.sR % 4 == 0 && al(a.res, 16))) return false;
   return true;
 }
@@ -405,14 +415,16 @@ int gemm_rs(const GemmSSArgs& a, int dbg, hipStream_t stream) {
   static const bool by_shape = getenv("LBM_PROF_SHAPES") != nullptr;
   std::string shaped;
   if (by_shape)
-    shaped = "gemm_rs " + std::to_string(a.M) + "x" + std::to_string(a.N) + "x" + std::to_string(a.K) + "x" + std::to_string(a.batch) +
+    shaped = std::string(a.planes == 1 ? "gemm_rh " : "gemm_rs ") + std::to_string(a.M) + "x" + std::to_string(a.N) + "x" + std::to_string(a.K) + "x" + std::to_string(a.batch) +
              (a.Y ? " f32" : "") + (a.Ys ? " split" : "");
   const double mnk = (double)a.M * a.N * a.K * a.batch;
-  ProfScope prof(by_shape ? intern_name(shaped.c_str()) : "gemm_rs", stream, 2.0 * mnk,
+  ProfScope prof(by_shape ? intern_name(shaped.c_str()) : a.planes == 1 ? "gemm_rh" : "gemm_rs", stream, 2.0 * mnk,
                  4.0 * ((double)a.M * a.K * a.batch + (double)a.N * a.K * (a.sB || a.batch == 1 ? a.batch : 1) +
                         (double)a.M * a.N * a.batch * ((a.Y ? 1 : 0) + (a.Ys ? 1 : 0) + (a.res ? 1 : 0))));
   const dim3 grid((unsigned)wgs), block(512);
-  if (a.res) hipLaunchKernelGGL((gemm_rs_kernel<0, 1, true, 0>), grid, block, 0, stream, d);
+  if (a.planes == 1) hipLaunchKernelGGL((gemm_rs_kernel<0, 1, false, 4, 1>), grid, block, 0, stream, d);
+  else if (a.res) hipLaunchKernelGGL((gemm_rs_kernel<0, 1, true, 0>), grid, block, 0, stream, d);
+  else if (a.Ys && a.ys_plane == 0) hipLaunchKernelGGL((gemm_rs_kernel<0, 1, false, 4>), grid, block, 0, stream, d);     // (never together with Y: see gemm_rs_ok)
   else if (a.Y && a.Ys) hipLaunchKernelGGL((gemm_rs_kernel<0, 1, false, 12>), grid, block, 0, stream, d);
   else if (a.Ys) hipLaunchKernelGGL((gemm_rs_kernel<0, 1, false, 8>), grid, block, 0, stream, d);
   else hipLaunchKernelGGL((gemm_rs_kernel<0, 1, false, 4>), grid, block, 0, stream, d);

@@ -416,3 +416,32 @@ def test_f16_memories_read_out_like_the_widened_memories(hip, R, S, head):
     a, va = hip.attn_readout(U, seq, S, ring_head=head, temb=temb, mask_a=ma, mask_b=mb, want_valid=True)
     b, vb = hip.attn_readout(U, seq.float(), S, ring_head=head, temb=temb, mask_a=ma, mask_b=mb, want_valid=True)
     assert torch.equal(a.view(torch.int32), b.view(torch.int32)) and torch.equal(va, vb)
+
+
+@pytest.mark.parametrize("M,N", [(40000, 1536), (33000, 256), (70001, 520)])
+def test_single_plane_row_streaming_product_with_f16_output(hip, M, N):
+    """The value projection of the f16-storage mode: hi planes only, plain f16 output (ys_plane = 0, no fp32 copy).  The row-streaming
+    kernel (debug key 2 = 512) against the tiled one (256): same MFMA order over k, so the same f16 bits; and both against fp64."""
+    lib = hip.load()
+    r = np.random.default_rng(M + N)
+    x = torch.from_numpy(r.normal(size=(M, 256)).astype(np.float32)).cuda()
+    w = torch.from_numpy((r.normal(size=(N, 256)) * 0.1).astype(np.float32)).cuda()
+    b = torch.from_numpy(r.normal(size=(N,)).astype(np.float32)).cuda()
+    xs, ws = _split(hip, x), hip.SplitWeight(w)
+    outs = {}
+    try:
+        for flag in (256, 512):
+            lib.lbm_hip_debug_set(2, flag)
+            y = torch.zeros(M, N, device="cuda", dtype=torch.float16)
+            hip.profile_begin()
+            hip.linear_ss_raw(A=xs.hi, a_plane=xs.plane, B=ws.hi, b_plane=0, bias=b.data_ptr(), Ys=y.data_ptr(), ys_plane=0, M=M, N=N, K=256,
+                              lda=256, ldb=256, ldys=N, batch=1, planes=1, res_scale=1.0)
+            names = {p["name"] for p in hip.profile_end()}
+            assert names == ({"gemm_rh"} if flag == 512 else {"gemm_sh<128,128,2,4,2>"}), names
+            outs[flag] = y
+    finally:
+        lib.lbm_hip_debug_set(2, 0)
+    assert torch.equal(outs[256].view(torch.int16), outs[512].view(torch.int16))
+    want = x.half().double() @ w.half().double().t() + b.double()
+    err = (outs[512].double() - want).abs().max().item()
+    assert err < 2e-2 * float(want.abs().max()) / 10 + 5e-3, err          # f16 output: 2^-11 relative

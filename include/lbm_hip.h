@@ -431,7 +431,8 @@ int lbm_hip_profile_end(lbm_hip_profile_entry* out, int32_t cap);
  * results are WRONG when set).  The ablation code exists only in the tuning build (`make -C lbm_amd/csrc tuning`, -DLBM_TUNING ->
  * liblbm_hip_tuning.so, see lbm_hip_tuning_build): the product library refuses those values with an error.
  *   1  force the split-GEMM tiling (1..23, gemm16.hip)          2  split-GEMM flags (256 = never / 512 = always the row-streaming
- *   3  attention read-out mode                                      kernel, 32 = no XCD remap, bits 12.. = its ablation switches)
+ *   3  attention read-out mode                                      kernel, 32 = no XCD remap, 1024 = the rows-stationary form of it (slower; kept for
+ *                                                                   the A/B), bits 12.. = its ablation switches)
  *   4  force the convolution tiling (1..14)                     5  dense top-k mode
  *   6  largest k fused into the tiled correlation product below 4096 rows (default 1)
  *   7  most rows for the few-rows fused feed-forward (default 2048)   8  feed-forward sites that may fuse (bit mask, default 63)

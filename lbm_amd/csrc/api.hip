@@ -871,7 +871,7 @@ int lbm_hip_debug_set(int32_t key, int32_t value) {
   // (`make tuning`, -DLBM_TUNING): the product library refuses them instead of silently doing nothing.
   const bool ablation = (key == 14 || key == 16 || key == 20 || key == 23) ? value != 0
                         : key == 18                           ? (value & 255) != 0
-                        : key == 2                            ? (value & ~0x3b0) != 0
+                        : key == 2                            ? (value & ~0x7f0) != 0
                                                               : false;
   if (ablation) {
     set_error("debug_set: key %d value %d selects timing-only ablation code, which this library was built without (make tuning)", key, value);

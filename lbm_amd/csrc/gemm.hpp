@@ -83,6 +83,9 @@ bool gemm_ss_topk_ok(int M, int N, int K, int batch, int k);   // would gemm_ss 
 // Row-streaming variant for K = 256 (gemm_rs.hip): B stationary in registers, A streamed through LDS; same arithmetic, bit-identical.
 bool gemm_rs_ok(const GemmSSArgs& a);
 int gemm_rs(const GemmSSArgs& a, int dbg, hipStream_t stream);
+// the same product with the ROWS stationary (activations in registers, weights streamed): many rows x many columns, fp32 output
+bool gemm_rs_rows_ok(const GemmSSArgs& a);
+int gemm_rs_rows(const GemmSSArgs& a, int dbg, hipStream_t stream);
 // ... and with the roles swapped for the correlation product + per-point top-k pre-selection: candidates per point
 // (gemm_rs_topk_cands tells how many, a multiple of 4) in cand_v / cand_i [batch * M, n_cand]
 int gemm_rs_topk_cands(int P0, int N, int batch, int k);

@@ -1062,6 +1062,10 @@ int gemm_ss(const GemmSSArgs& a, hipStream_t stream) {
   int t = g_force_tile16;
   // K = 256 and many rows: the row-streaming kernel (weights stationary in registers), gemm_rs.hip.  Debug flags: 256 = never,
   // 512 = whenever the shape admits it.
+  // rows-stationary form (gemm_rs EPI 2): built and measured in round 3, bit-identical, SLOWER on the value projection it was meant
+  // for (3.44 against 3.03 ms at 1 044 480 x 1536 x 256: with lanes = rows every store instruction touches 32 different lines) --
+  // reachable only with debug flag 1024
+  if (t == 0 && (g_dbg16 & 1024) && gemm_rs_rows_ok(a)) return gemm_rs_rows(a, (g_dbg16 >> 12) & 0xffff, stream);
   if (t == 0 && !(g_dbg16 & 256) && gemm_rs_ok(a) && ((g_dbg16 & 512) || a.M >= g_rs_min_rows))
     return gemm_rs(a, (g_dbg16 >> 12) & 0xffff, stream);
   const long long mid = (long long)((a.M + 63) / 64) * ((a.N + 63) / 64) * a.batch;

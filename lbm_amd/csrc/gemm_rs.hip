@@ -205,7 +205,7 @@ __global__ __launch_bounds__(512) void gemm_rs_kernel(GemmRSDev a) {
       } else if constexpr (EPI == 0) {       // (activations hi x weights lo) then (activations lo x weights hi): the tiled kernel's order
         acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[g & 1][2 * q], fbl[ks], first ? zero16 : acx, 0, 0, 0);
         acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[g & 1][2 * q + 1], fbh[ks], acx, 0, 0, 0);
-      } else {                        // roles swapped (S = map, T = points): (points hi x map lo) then (points lo x map hi), as there
+      } else {                        // roles swapped (EPI 1: S = map, T = points; EPI 2: S = weights, T = token rows): (stationary hi x streamed lo) then (stationary lo x streamed hi), as there
         acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[g & 1][2 * q + 1], fbh[ks], first ? zero16 : acx, 0, 0, 0);
         acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[g & 1][2 * q], fbl[ks], acx, 0, 0, 0);
       }
@@ -229,6 +229,7 @@ __global__ __launch_bounds__(512) void gemm_rs_kernel(GemmRSDev a) {
     Yh = a.Ys ? a.Ys + (long long)z * a.sYs : nullptr;
     res = (RES && a.res) ? a.res + (long long)z * a.sR : nullptr;
   }
+  if constexpr (EPI == 2) Y = a.Y + (long long)z * a.sY;
   // epilogue of one finished step, out of the saved registers
   auto epi = [&](const int step) __attribute__((always_inline)) {
     const int mb = (s0 + step) * 32;
@@ -288,6 +289,36 @@ __global__ __launch_bounds__(512) void gemm_rs_kernel(GemmRSDev a) {
             if (a.ys_plane) st8_asm(yp + a.ys_plane, sl, nt);       // (ys_plane 0: plain f16 output, the hi plane alone)
           }
         }
+      }
+      asm volatile("" ::: "memory");
+    } else if constexpr (EPI == 2) {
+      // Rows stationary: lane (r, h) holds, for ITS row n0 + r, the 16 outputs of columns mb + 4 h + (e & 3) + 8 (e >> 2) -- four runs
+      // of four consecutive columns, i.e. four 16-byte stores straight out of the accumulator layout: no transposition through LDS.
+      // Over the steps a wave walks along its 32 output rows, 128 bytes further per step.
+      if (n0 + r < a.Nt) {
+        float* yp = Y + (long long)(n0 + r) * a.ldy + mb + 4 * h;
+        const float* bp = a.bias ? a.bias + (long long)z * a.sBias + mb + 4 * h : nullptr;
+        f32x4 v4[4];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          v4[g4] = f32x4{out[4 * g4], out[4 * g4 + 1], out[4 * g4 + 2], out[4 * g4 + 3]};
+          if (bp) {
+            const float4 b4 = ld4(bp + 8 * g4);
+            v4[g4][0] += b4.x; v4[g4][1] += b4.y; v4[g4][2] += b4.z; v4[g4][3] += b4.w;
+          }
+        }
+        // ONE asm block for the four stores, each from its own register quad, and wait states behind the last: a 16-byte store
+        // reads its data registers over several cycles after issue, and the compiler -- which cannot see that this asm is a store
+        // -- would otherwise rebuild the next quad in the same registers at once (seen: columns 8 g + {0, 1} of some lanes
+        // carrying the NEXT store's values).
+        if (nt)
+          asm volatile("global_store_dwordx4 %0, %1, off nt\n\tglobal_store_dwordx4 %0, %2, off offset:32 nt\n\t"
+                       "global_store_dwordx4 %0, %3, off offset:64 nt\n\tglobal_store_dwordx4 %0, %4, off offset:96 nt\n\ts_nop 3"
+                       ::"v"(yp), "v"(v4[0]), "v"(v4[1]), "v"(v4[2]), "v"(v4[3]) : "memory");
+        else
+          asm volatile("global_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx4 %0, %2, off offset:32\n\t"
+                       "global_store_dwordx4 %0, %3, off offset:64\n\tglobal_store_dwordx4 %0, %4, off offset:96\n\ts_nop 3"
+                       ::"v"(yp), "v"(v4[0]), "v"(v4[1]), "v"(v4[2]), "v"(v4[3]) : "memory");
       }
       asm volatile("" ::: "memory");
     } else {
@@ -429,6 +460,35 @@ int gemm_rs(const GemmSSArgs& a, int dbg, hipStream_t stream) {
   else if (a.Ys) hipLaunchKernelGGL((gemm_rs_kernel<0, 1, false, 8>), grid, block, 0, stream, d);
   else hipLaunchKernelGGL((gemm_rs_kernel<0, 1, false, 4>), grid, block, 0, stream, d);
   return check_launch("gemm_rs");
+}
+
+// Linear layer with the ROWS stationary (EPI 2): a workgroup keeps 256 rows of the activations in registers for its whole life --
+// they are read from memory exactly once, by ordinary loads -- and the weight matrix (small: it stays in every L2) streams through
+// the LDS ring; a lane owns an output row, so the results leave as 16-byte pieces of whole rows with no transposition.  For products
+// with many rows and many columns (the value projection: 1 044 480 x 1536 x 256): there the weights-stationary form reads the
+// activations once per 256-column slice (2.36 GB for 1.07) and writes 1-KB pieces 6 KB apart.
+bool gemm_rs_rows_ok(const GemmSSArgs& a) {
+  auto al = [](const void* p, uintptr_t m) { return ((uintptr_t)p & (m - 1)) == 0; };
+  return a.planes == 2 && a.K == 256 && a.topk_k == 0 && a.N % 32 == 0 && a.N >= 32 && a.M >= 256 && a.Y && !a.Ys && !a.res &&
+         a.act == ACT_NONE && a.ldy % 4 == 0 && a.sY % 4 == 0 && al(a.Y, 16) && (!a.bias || al(a.bias, 16)) && a.sBias % 4 == 0;
+}
+
+int gemm_rs_rows(const GemmSSArgs& a, int dbg, hipStream_t stream) {
+  LBM_REQUIRE(gemm_rs_rows_ok(a), "gemm_rs_rows: shape / alignment not supported");
+  GemmRSDev d{};
+  // roles: streamed S = the weights [N, 256], stationary T = the activation rows [M, 256]
+  d.S = (const _Float16*)a.B; d.T = (const _Float16*)a.A; d.s_plane = a.b_plane; d.t_plane = a.a_plane; d.sS = a.sB; d.sT = a.sA;
+  d.lds = a.ldb; d.ldt = a.lda; d.Ms = a.N; d.Nt = a.M; d.batch = a.batch;
+  d.bias = a.bias; d.sBias = a.sBias; d.Y = a.Y; d.sY = a.sY; d.ldy = a.ldy;
+  d.dbg = dbg;
+  rs_partition(d, 96, false);
+  // (with few row slices the weight rows are cut into chunks so that every CU has work: each chunk writes its own columns)
+  const long long wgs = rs_grid(d);
+  LBM_REQUIRE(wgs <= 0x7fffffffLL, "gemm_rs_rows: grid too large");
+  const double mnk = (double)a.M * a.N * a.K * a.batch;
+  ProfScope prof("gemm_rs_rows", stream, 2.0 * mnk, 4.0 * ((double)a.M * a.K * a.batch + (double)a.N * a.K + (double)a.M * a.N * a.batch));
+  hipLaunchKernelGGL((gemm_rs_kernel<2, 1, false, 4>), dim3((unsigned)wgs), dim3(512), 0, stream, d);
+  return check_launch("gemm_rs_rows");
 }
 
 // Correlation + per-point top-k pre-selection.  points: split planes [batch, N, 256]; map: split planes [batch, P0, 256].

@@ -445,3 +445,28 @@ def test_single_plane_row_streaming_product_with_f16_output(hip, M, N):
     want = x.half().double() @ w.half().double().t() + b.double()
     err = (outs[512].double() - want).abs().max().item()
     assert err < 2e-2 * float(want.abs().max()) / 10 + 5e-3, err          # f16 output: 2^-11 relative
+
+
+@pytest.mark.parametrize("M,N", [(33000, 1536), (5000, 1024), (256, 32), (40001, 96), (70000, 2048)])
+def test_rows_stationary_product_equals_the_tiled_product(hip, M, N):
+    """gemm_rs EPI 2 (activation rows stationary in registers, weights streamed, 16-byte row stores straight from the accumulators:
+    the value projection's form) against the tiled kernel: same split arithmetic in the same order, so the same bits."""
+    lib = hip.load()
+    r = np.random.default_rng(M * 7 + N)
+    xs = _split(hip, torch.from_numpy(r.normal(size=(M, 256)).astype(np.float32)).cuda())
+    ws = hip.SplitWeight(torch.from_numpy((r.normal(size=(N, 256)) * 0.1).astype(np.float32)).cuda())
+    b = torch.from_numpy(r.normal(size=(N,)).astype(np.float32)).cuda()
+    outs = {}
+    try:
+        for flag, want in ((256, None), (1024, "gemm_rs_rows")):
+            lib.lbm_hip_debug_set(2, flag)
+            for bias in (b, None):
+                hip.profile_begin()
+                y, _ = hip.linear_ss(xs, ws, bias)
+                names = {p["name"] for p in hip.profile_end()}
+                assert want is None or names == {want}, names
+                outs[(flag, bias is None)] = y
+    finally:
+        lib.lbm_hip_debug_set(2, 0)
+    for nb in (False, True):
+        assert torch.equal(outs[(256, nb)].view(torch.int32), outs[(1024, nb)].view(torch.int32)), (M, N, nb)

@@ -68,12 +68,15 @@ __device__ __forceinline__ void wait_vm() {
 
 // Output stores of the in-loop epilogue go out through inline asm.  As compiler-visible stores they put a second kind of event on the
 // VM counter beside the LDS-DMA loads; hipcc then treats the counter as out of order and drains it (vmcnt(0)) at every register it
-// believes pending -- four times per step, which serialises the DMA ring (seen in the ISA).  gfx9 reads store data at issue, so the
-// data registers may be overwritten right away; completion is covered by the hand-counted waits of the step loop.
+// believes pending -- four times per step, which serialises the DMA ring (seen in the ISA).  Completion is covered by the hand-counted
+// waits of the step loop; the data registers are protected by the wait states inside the asm string (below).
 __device__ __forceinline__ void st16_asm(float* p, const float4 v, const bool nt) {
   const f32x4 d = {v.x, v.y, v.z, v.w};
-  if (nt) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(d) : "memory");
-  else asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(d) : "memory");
+  // (`s_nop 1` inside the string: a 16-byte store reads its data registers over two more cycles, and hipcc -- which cannot see that
+  // this asm is a store -- may rebuild the next value in them at once.  Round 3 met exactly that in the rows-stationary epilogue:
+  // columns {0, 1} of some lanes carried the NEXT store's values.)
+  if (nt) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(d) : "memory");
+  else asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(d) : "memory");
 }
 __device__ __forceinline__ void st8_asm(_Float16* p, const half4 d, const bool nt) {
   if (nt) asm volatile("global_store_dwordx2 %0, %1, off nt" ::"v"(p), "v"(d) : "memory");

@@ -446,7 +446,12 @@ int lbm_hip_profile_end(lbm_hip_profile_entry* out, int32_t cap);
  *  20  stem_pool timing-only ablation bits (results are wrong when set): 1 no DMA after the prologue, 2 no pooling / stores,
  *      4 no MFMAs, 8 no hand-over writes (default 0)
  *  21  msda_sample with a batch of streams: 1 (default) workgroups dealt so that each XCD works through one stream's value map
- *      at a time, 0 dispatch order                                                                                            */
+ *      at a time, 0 dispatch order
+ *  22  deformable-sampling kernels (bit mask, default 3): 1 = LDS-window kernel for the k = 9 / 4 lattice launches, 2 = tap-table
+ *      kernel for the k = 1 launches; 0 = the direct gather everywhere (bit-identical rows, the A/B of DESIGN.md section 5)
+ *  23  msda_window timing-only ablation bits (tuning build): 1 no tap table, 2 no staging, 4 no accumulation, 8 no prologue reductions
+ *  24  encoder tail workgroup order: 1 (default) the same 8 x 8 block of every stream back to back, 0 stream by stream
+ *  25  gemm_rs LDS ring: 3 (default) or 4 stages (steps fetched two / three ahead); bit-identical, measured equal             */
 int lbm_hip_debug_set(int32_t key, int32_t value);
 /* The knobs that currently differ from their defaults (what a measurement must state beside its figure; bench.py prints them
  * in `config.knobs` and refuses a headline when any is set): writes up to `cap` (key, value) pairs, returns how many there are. */

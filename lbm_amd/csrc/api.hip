@@ -175,6 +175,7 @@ extern int g_msda_xcd;              // msda.hip (debug key 21)
 extern int g_msda_window;           // msda.hip (debug key 22)
 extern int g_msda_dbg;              // msda.hip (debug key 23)
 extern int g_tail_order;            // pyramid.hip (debug key 24)
+extern int g_rs_ring;               // gemm_rs.hip (debug key 25)
 static int g_head_pair = 1;         // tuning (debug key 17): 0 = offset and visibility heads as two separate chains
 static int g_ffn_rows_mode = 0;     // tuning (debug key 15): 0 = many-rows fused feed-forward from g_ffn_fused_rows + 1 rows on, 1 = never, 2 = for any row count
 static int g_ffn_fused_rows = 2048; // tuning (debug key 7): most rows for which the feed-forward runs as one fused launch (0: never)
@@ -185,7 +186,7 @@ static std::map<int, int> g_knobs;
 static int knob_default(int key) {
   switch (key) {
     case 6: case 13: case 17: case 21: case 24: return 1;
-    case 22: return 3;
+    case 22: case 25: return 3;
     case 7: return 2048;
     case 8: return 63;
     default: return 0;
@@ -952,6 +953,14 @@ int lbm_hip_debug_set(int32_t key, int32_t value) {
   }
   if (key == 24) {
     lbm::g_tail_order = value;
+    return 0;
+  }
+  if (key == 25) {
+    if (value != 3 && value != 4) {
+      set_error("debug_set: key 25 (gemm_rs ring stages) takes 3 or 4");
+      return -1;
+    }
+    lbm::g_rs_ring = value;
     return 0;
   }
   if (key == 18) {

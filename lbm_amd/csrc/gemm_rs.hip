@@ -56,14 +56,8 @@ typedef __attribute__((address_space(3))) void* lds_ptr_rs;
 
 template <int N>
 __device__ __forceinline__ void wait_vm() {
-  static_assert(N == 0 || N == 2 || N == 4 || N == 6 || N == 8 || N == 12 || N == 16, "unsupported vmcnt");
-  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter on gfx9");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 // Output stores of the in-loop epilogue go out through inline asm.  As compiler-visible stores they put a second kind of event on the
@@ -88,12 +82,16 @@ __device__ __forceinline__ void st8_asm(_Float16* p, const half4 d, const bool n
 // leave the previous epilogue's stores in flight (gfx9 retires the VM counter in issue order)
 // NPL: operand planes multiplied.  2 = split operands, three MFMAs per block (fp32-grade); 1 = the hi planes only (plain f16
 // operands: the f16-storage mode's value projection) -- the lo planes are neither fetched nor multiplied (EPI 0 only)
-template <int EPI, int KM, bool RES = false, int NST = 0, int NPL = 2>
+// RING: stages of the LDS ring (3 or 4).  4 = steps fetched THREE ahead: the wait at the top of a step then leaves two steps' stores and
+// DMA pieces in flight instead of one (the linear epilogue's patches lose their padding so that 4 x 32 KB + 8 x 4 KB is exactly the
+// CU's 160 KB)
+template <int EPI, int KM, bool RES = false, int NST = 0, int NPL = 2, int RING = 3>
 __global__ __launch_bounds__(512) void gemm_rs_kernel(GemmRSDev a) {
   static_assert(NPL == 2 || EPI == 0, "single-plane form: linear epilogue only");
   constexpr int NP = 2 * NPL;                         // LDS-DMA pieces a wave issues per step
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int STAGE = 32768, NS = 3, TP = 36;
+  static_assert(RING == 3 || RING == 4, "ring of 3 or 4 stages");
+  constexpr int STAGE = 32768, NS = RING, D = RING - 1, TP = RING == 4 ? 32 : 36;      // D: steps fetched ahead
   constexpr int LDS_BYTES = NS * STAGE + (EPI == 0 ? 8 * 32 * TP * 4 : 0);
   __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
@@ -163,8 +161,9 @@ __global__ __launch_bounds__(512) void gemm_rs_kernel(GemmRSDev a) {
       __builtin_amdgcn_global_load_lds(g, (lds_ptr_rs)dst, 16, 0, 0);
     }
   };
-  issue(0, 0);
-  if (ns > 1) issue(1, 1);
+#pragma unroll
+  for (int j = 0; j < D; ++j)
+    if (ns > j) issue(j, j);
 
   const int sw = (r >> 2) & 3;
   const int o0 = r * 64 + ((h ^ sw) << 4), o1 = r * 64 + (((2 + h) ^ sw) << 4);
@@ -259,15 +258,14 @@ __global__ __launch_bounds__(512) void gemm_rs_kernel(GemmRSDev a) {
         asm volatile(
             "s_waitcnt lgkmcnt(0)\n\t"
             "ds_read_b128 %0, %4\n\t"
-            "ds_read_b128 %1, %4 offset:1152\n\t"
-            "ds_read_b128 %2, %4 offset:2304\n\t"
-            "ds_read_b128 %3, %4 offset:3456\n\t"
+            "ds_read_b128 %1, %4 offset:%5\n\t"
+            "ds_read_b128 %2, %4 offset:%6\n\t"
+            "ds_read_b128 %3, %4 offset:%7\n\t"
             "s_waitcnt lgkmcnt(0)"
             : "=&v"(tv[0]), "=&v"(tv[1]), "=&v"(tv[2]), "=&v"(tv[3])
-            : "v"(ta)
+            : "v"(ta), "n"(8 * TP * 4), "n"(16 * TP * 4), "n"(24 * TP * 4)          // eight rows of the patch per read
             : "memory");
       }
-      static_assert(8 * TP * 4 == 1152, "patch pitch and the asm offsets above go together");
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int rl = i * 8 + (lane >> 3), c4 = lane & 7;
@@ -351,16 +349,21 @@ __global__ __launch_bounds__(512) void gemm_rs_kernel(GemmRSDev a) {
   // them pending on the loop's back edge and drains the whole DMA pipeline (vmcnt(0)) before the first MFMA of every step.
   __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0), expcnt / lgkmcnt untouched
   for (int s = 0; s < ns; ++s) {
-    // Step s must have landed.  In issue order this wave's VM queue holds, after the 4 pieces of step s: the NST output stores of the
-    // epilogue of step s - 2 (issued during step s - 1; full steps only, so their number is fixed) and the 4 pieces of step s + 1.
-    // The counter retires in issue order, so "at most NST + 4 outstanding" means step s is in while those stay in flight.  Waves
-    // without columns issue no stores; with a residual the compiler's own waits for the residual loads drain the queue anyway.
-    const bool more = s + 1 < ns;
-    if (s >= 2 && active && !RES && NST > 0 && !(LBM_ABL(a.dbg & 128))) {
-      if (more) wait_vm<NST + NP>();
-      else wait_vm<NST>();
+    // Step s must have landed.  Iteration i of this loop issues, in this order, the NST output stores of the epilogue of step i - 1
+    // (i >= 1; full steps only, so their number is fixed) and the NP pieces of step i + D (while there is one); step s itself was
+    // issued in iteration s - D (or before the loop).  So behind the pieces of step s this wave's VM queue holds what iterations
+    // s - D + 1 .. s - 1 issued: (D - 1) x NST stores and min(D - 1, ns - 1 - s) x NP pieces.  The counter retires in issue order, so
+    // "at most that many outstanding" means step s is in while those stay in flight.  Waves without columns issue no stores; with a
+    // residual the compiler's own waits for the residual loads drain the queue anyway.
+    const int ahead = min(D - 1, ns - 1 - s);          // later steps already requested
+    const bool counted = s >= D && active && !RES && NST > 0 && !(LBM_ABL(a.dbg & 128));
+    if (counted) {
+      if (ahead == D - 1) wait_vm<(D - 1) * (NST + NP)>();
+      else if (D == 3 && ahead == 1) wait_vm<(D - 1) * NST + NP>();
+      else wait_vm<(D - 1) * NST>();
     } else {
-      if (more) wait_vm<NP>();
+      if (ahead == D - 1) wait_vm<(D - 1) * NP>();
+      else if (D == 3 && ahead == 1) wait_vm<NP>();
       else wait_vm<0>();
     }
     if (!(LBM_ABL(a.dbg & 2048))) __builtin_amdgcn_s_barrier();          // every wave's pieces of step s are in; every wave is done reading step s - 1
@@ -369,12 +372,12 @@ __global__ __launch_bounds__(512) void gemm_rs_kernel(GemmRSDev a) {
     if (mm) ldg(Ab, 0, 0);                 // in flight under the epilogue / DMA issue below
     if (!skew) {
       if (active && s > 0) epi(s - 1);
-      if (s + 2 < ns && !(LBM_ABL(a.dbg & 2))) issue((s + 2) % NS, s + 2);
+      if (s + D < ns && !(LBM_ABL(a.dbg & 2))) issue((s + D) % NS, s + D);
     }
     if (mm) half_step(Ab, 0);
     if (skew) {
       if (active && s > 0) epi(s - 1);
-      if (s + 2 < ns && !(LBM_ABL(a.dbg & 2))) issue((s + 2) % NS, s + 2);
+      if (s + D < ns && !(LBM_ABL(a.dbg & 2))) issue((s + D) % NS, s + D);
     }
     if (mm) half_step(Ab, 4);
     if (active) {
@@ -398,6 +401,7 @@ __global__ __launch_bounds__(512) void gemm_rs_kernel(GemmRSDev a) {
 }
 
 static int g_rs_cus = 256;
+int g_rs_ring = 3;     // debug key 25: stages of the LDS ring (3 | 4), bit-identical results; see RING above
 
 // steps of 32 streamed rows per workgroup: about one workgroup per CU, at most `cap` steps each (the 2-step cost of loading the
 // stationary fragments is amortised; more, shorter workgroups balance better)
@@ -456,12 +460,18 @@ int gemm_rs(const GemmSSArgs& a, int dbg, hipStream_t stream) {
                  4.0 * ((double)a.M * a.K * a.batch + (double)a.N * a.K * (a.sB || a.batch == 1 ? a.batch : 1) +
                         (double)a.M * a.N * a.batch * ((a.Y ? 1 : 0) + (a.Ys ? 1 : 0) + (a.res ? 1 : 0))));
   const dim3 grid((unsigned)wgs), block(512);
-  if (a.planes == 1) hipLaunchKernelGGL((gemm_rs_kernel<0, 1, false, 4, 1>), grid, block, 0, stream, d);
+  const bool r4 = g_rs_ring == 4;
+#define LBM_RS_LAUNCH(...)                                                                          \
+  do {                                                                                              \
+    if (r4) hipLaunchKernelGGL((gemm_rs_kernel<__VA_ARGS__, 4>), grid, block, 0, stream, d);        \
+    else hipLaunchKernelGGL((gemm_rs_kernel<__VA_ARGS__, 3>), grid, block, 0, stream, d);           \
+  } while (0)
+  if (a.planes == 1) LBM_RS_LAUNCH(0, 1, false, 4, 1);
   else if (a.res) hipLaunchKernelGGL((gemm_rs_kernel<0, 1, true, 0>), grid, block, 0, stream, d);
-  else if (a.Ys && a.ys_plane == 0) hipLaunchKernelGGL((gemm_rs_kernel<0, 1, false, 4>), grid, block, 0, stream, d);     // (never together with Y: see gemm_rs_ok)
-  else if (a.Y && a.Ys) hipLaunchKernelGGL((gemm_rs_kernel<0, 1, false, 12>), grid, block, 0, stream, d);
-  else if (a.Ys) hipLaunchKernelGGL((gemm_rs_kernel<0, 1, false, 8>), grid, block, 0, stream, d);
-  else hipLaunchKernelGGL((gemm_rs_kernel<0, 1, false, 4>), grid, block, 0, stream, d);
+  else if (a.Ys && a.ys_plane == 0) LBM_RS_LAUNCH(0, 1, false, 4, 2);     // (never together with Y: see gemm_rs_ok)
+  else if (a.Y && a.Ys) LBM_RS_LAUNCH(0, 1, false, 12, 2);
+  else if (a.Ys) LBM_RS_LAUNCH(0, 1, false, 8, 2);
+  else LBM_RS_LAUNCH(0, 1, false, 4, 2);
   return check_launch("gemm_rs");
 }
 
@@ -520,9 +530,12 @@ int gemm_rs_topk(const GemmSSArgs& a, int dbg, hipStream_t stream) {
   const double mnk = (double)a.M * a.N * a.K * a.batch;
   ProfScope prof(KM == 1 ? "gemm_rs_topk1" : KM == 4 ? "gemm_rs_topk4" : "gemm_rs_topk9", stream, 2.0 * mnk,
                  4.0 * ((double)a.M * a.K * a.batch + (double)a.N * a.K * a.batch) + 8.0 * (double)a.M * a.batch * d.n_cand);
-  if (KM == 1) hipLaunchKernelGGL((gemm_rs_kernel<1, 1>), dim3((unsigned)wgs), dim3(512), 0, stream, d);
-  else if (KM == 4) hipLaunchKernelGGL((gemm_rs_kernel<1, 4>), dim3((unsigned)wgs), dim3(512), 0, stream, d);
-  else hipLaunchKernelGGL((gemm_rs_kernel<1, 9>), dim3((unsigned)wgs), dim3(512), 0, stream, d);
+  const dim3 grid((unsigned)wgs), block(512);
+  const bool r4 = g_rs_ring == 4;
+  if (KM == 1) LBM_RS_LAUNCH(1, 1, false, 0, 2);
+  else if (KM == 4) LBM_RS_LAUNCH(1, 4, false, 0, 2);
+  else LBM_RS_LAUNCH(1, 9, false, 0, 2);
+#undef LBM_RS_LAUNCH
   return check_launch("gemm_rs_topk");
 }
 

@@ -26,9 +26,11 @@ def _split(hip, x):
     return t
 
 
+@pytest.mark.parametrize("ring", [3, 4])           # debug key 25: stages of the row-streaming kernel's LDS ring (steps fetched 2 / 3 ahead)
 @pytest.mark.parametrize("M,N", [(4100, 256), (33, 1456), (5000, 432), (40000, 1024), (1, 256), (31, 8), (257, 260)])
-def test_linear_is_bit_identical_to_the_tiled_product(hip, M, N):
+def test_linear_is_bit_identical_to_the_tiled_product(hip, M, N, ring):
     lib = hip.load()
+    lib.lbm_hip_debug_set(25, ring)
     r = np.random.default_rng(M + N)
     xs = _split(hip, torch.from_numpy(r.normal(size=(M, 256)).astype(np.float32)).cuda())
     ws = hip.SplitWeight(torch.from_numpy((r.normal(size=(N, 256)) * 0.1).astype(np.float32)).cuda())
@@ -47,6 +49,7 @@ def test_linear_is_bit_identical_to_the_tiled_product(hip, M, N):
                 assert torch.equal(s0.view(torch.int16), s1.view(torch.int16)), (act, use_res)
     finally:
         lib.lbm_hip_debug_set(2, 0)
+        lib.lbm_hip_debug_set(25, 3)
 
 
 def _dense(hip, q, F, k, grid_w):
@@ -69,12 +72,17 @@ def _dense(hip, q, F, k, grid_w):
 
 
 @pytest.mark.parametrize("B,N,h,w,k", [(1, 1024, 96, 128, 9), (3, 300, 40, 52, 4), (2, 37, 24, 32, 1), (64, 64, 16, 24, 9), (1, 2600, 48, 64, 9)])
-def test_correlation_top_k_equals_dense_product_and_dense_top_k(hip, B, N, h, w, k):
+@pytest.mark.parametrize("ring", [3, 4])
+def test_correlation_top_k_equals_dense_product_and_dense_top_k(hip, B, N, h, w, k, ring):
     g = torch.Generator().manual_seed(B * 1000 + N)
     qf = torch.nn.functional.normalize(torch.randn(B, N, 256, generator=g), dim=-1).cuda()
     Ff = (torch.randn(B, h * w, 256, generator=g) * 0.3).cuda()
     q, F = _split(hip, qf), _split(hip, Ff)
-    idx, ref, val = hip.corr_topk(q, F, k, w)
+    hip.load().lbm_hip_debug_set(25, ring)
+    try:
+        idx, ref, val = hip.corr_topk(q, F, k, w)
+    finally:
+        hip.load().lbm_hip_debug_set(25, 3)
     di, dr, dv = _dense(hip, q, F, k, w)
     assert torch.equal(idx, di.view_as(idx))
     assert torch.equal(val.view(torch.int32), dv.view_as(val).view(torch.int32))

@@ -67,7 +67,12 @@ __device__ __forceinline__ float row_inv_norm(const float4 x) {
 // With many blocks MODE 2 runs with NW = 8 waves per workgroup (each wave takes two of the sixteen 2 x 2 groups and two of the sixteen
 // MFMA blocks in turn): at ~94 VGPRs a 16-wave workgroup is alone on its CU and its load / multiply / pool / store phases run back to back; two
 // 8-wave workgroups per CU overlap them (1027 -> 922 us at 64 frames; one frame has fewer blocks than CUs and keeps 16 waves).
-template <int MODE, int NW = 16>
+// PATCH (TAIL forms): the bilinear footprints of a 2 x 2 group's four cells overlap almost entirely -- a 3 x 3 patch of q2 rows and
+// ONE 2 x 2 patch of q3 rows (a 2-aligned pair of fine cells never straddles a coarse source pair) -- so the group fetches 13 rows
+// where cell-by-cell evaluation fetched 32 (the same observation as corr_maps_block_kernel).  Weights stay up_coeff's, per cell;
+// positions come from the patch: at the borders up_coeff's clamped pair and the patch pair differ only where the weight is 0, so the
+// tokens are the same bits (debug key 24 bit 1 selects the cell-by-cell form for the A/B and the bit-identity test).
+template <int MODE, int NW = 16, bool PATCH = true>
 __global__ __launch_bounds__(NW * 64) void pyramid_pool_kernel(float* __restrict__ tok, int B, int h, int w, int L, void* toks,
                                                             long long toks_plane, TailArgs ta) {
   constexpr bool TAIL = MODE != 0;
@@ -92,6 +97,10 @@ __global__ __launch_bounds__(NW * 64) void pyramid_pool_kernel(float* __restrict
   const long long sbase = (long long)b * L * LBM_C + lane * 4;
   if constexpr (MODE == 2) {
 #if defined(__HIP_DEVICE_COMPILE__)
+   // (NW = 8: a wave's two blocks are the two row blocks of ONE column block -- q & 7 == wv for both -- so its weight fragments
+   // and bias are fetched once)
+   half8 bh[4], bl[4];
+   float bv = 0.f;
 #pragma unroll 1
    for (int gi = 0; gi < GPW; ++gi) {
     const int q = wv + gi * NW;
@@ -100,15 +109,20 @@ __global__ __launch_bounds__(NW * 64) void pyramid_pool_kernel(float* __restrict
     const long long row = (long long)b * P0 + (long long)(by * 8 + (c >> 3)) * w + bx * 8 + (c & 7);
     const _Float16* ap = ta.f1 + row * 64 + 8 * hh;
     const long long wo = (long long)(32 * cbk + r) * ta.ldw1 + 8 * hh;
-    half8 ah[4], al[4], bh[4], bl[4];
+    half8 ah[4], al[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       ah[ks] = *reinterpret_cast<const half8*>(ap + ks * 16);
       al[ks] = *reinterpret_cast<const half8*>(ap + ta.f1_plane + ks * 16);
-      bh[ks] = *reinterpret_cast<const half8*>(ta.w1h + wo + ks * 16);
-      bl[ks] = *reinterpret_cast<const half8*>(ta.w1l + wo + ks * 16);
     }
-    const float bv = ta.b1 ? ta.b1[32 * cbk + r] : 0.f;
+    if (gi == 0 || NW != 8) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        bh[ks] = *reinterpret_cast<const half8*>(ta.w1h + wo + ks * 16);
+        bl[ks] = *reinterpret_cast<const half8*>(ta.w1l + wo + ks * 16);
+      }
+      bv = ta.b1 ? ta.b1[32 * cbk + r] : 0.f;
+    }
     f32x16 acc, acx;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = acx[e] = 0.f;
@@ -156,12 +170,41 @@ __global__ __launch_bounds__(NW * 64) void pyramid_pool_kernel(float* __restrict
     auto bil = [](const float* qq, int wl, int ya, int yb, int xa, int xb, float lya, float lyb, float lxa, float lxb) {
       const float4 v00 = ld4(qq + (long long)(ya * wl + xa) * LBM_C), v01 = ld4(qq + (long long)(ya * wl + xb) * LBM_C);
       const float4 v10 = ld4(qq + (long long)(yb * wl + xa) * LBM_C), v11 = ld4(qq + (long long)(yb * wl + xb) * LBM_C);
-      float4 r;
-      r.x = lya * (lxa * v00.x + lxb * v01.x) + lyb * (lxa * v10.x + lxb * v11.x);
-      r.y = lya * (lxa * v00.y + lxb * v01.y) + lyb * (lxa * v10.y + lxb * v11.y);
-      r.z = lya * (lxa * v00.z + lxb * v01.z) + lyb * (lxa * v10.z + lxb * v11.z);
-      r.w = lya * (lxa * v00.w + lxb * v01.w) + lyb * (lxa * v10.w + lxb * v11.w);
-      return r;
+      // every rounding spelled out: the cell-by-cell and the patch form must give the same bits, whatever hipcc would contract
+      auto one = [&](float a00, float a01, float a10, float a11) {
+        const float top = __fmaf_rn(lxb, a01, __fmul_rn(lxa, a00)), bot = __fmaf_rn(lxb, a11, __fmul_rn(lxa, a10));
+        return __fmaf_rn(lyb, bot, __fmul_rn(lya, top));
+      };
+      return make_float4(one(v00.x, v01.x, v10.x, v11.x), one(v00.y, v01.y, v10.y, v11.y), one(v00.z, v01.z, v10.z, v11.z),
+                         one(v00.w, v01.w, v10.w, v11.w));
+    };
+    // PATCH: every row of the group requested before anything is used
+    float4 p2[3][3], p3[2][2];
+    if constexpr (PATCH) {
+      const int iy = y0 >> 1, ix = x0 >> 1;
+      const int ry[3] = {max(iy - 1, 0), iy, min(iy + 1, h2 - 1)};
+      const int rx[3] = {max(ix - 1, 0), ix, min(ix + 1, w2 - 1)};
+#pragma unroll
+      for (int u = 0; u < 3; ++u)
+#pragma unroll
+        for (int v2 = 0; v2 < 3; ++v2) p2[u][v2] = ld4(q2 + (long long)(ry[u] * w2 + rx[v2]) * LBM_C);
+      int yc, yd, xc, xd;
+      float t0, t1;
+      up_coeff(y0, 2, h4, yc, yd, t0, t1);
+      up_coeff(x0, 2, w4, xc, xd, t0, t1);
+      p3[0][0] = ld4(q3 + (long long)(yc * w4 + xc) * LBM_C);
+      p3[0][1] = ld4(q3 + (long long)(yc * w4 + xd) * LBM_C);
+      p3[1][0] = ld4(q3 + (long long)(yd * w4 + xc) * LBM_C);
+      p3[1][1] = ld4(q3 + (long long)(yd * w4 + xd) * LBM_C);
+    }
+    auto bilv = [](const float4& v00, const float4& v01, const float4& v10, const float4& v11, float lya, float lyb, float lxa, float lxb) {
+      // every rounding spelled out: the cell-by-cell and the patch form must give the same bits, whatever hipcc would contract
+      auto one = [&](float a00, float a01, float a10, float a11) {
+        const float top = __fmaf_rn(lxb, a01, __fmul_rn(lxa, a00)), bot = __fmaf_rn(lxb, a11, __fmul_rn(lxa, a10));
+        return __fmaf_rn(lyb, bot, __fmul_rn(lya, top));
+      };
+      return make_float4(one(v00.x, v01.x, v10.x, v11.x), one(v00.y, v01.y, v10.y, v11.y), one(v00.z, v01.z, v10.z, v11.z),
+                         one(v00.w, v01.w, v10.w, v11.w));
     };
 #pragma unroll
     for (int dy = 0; dy < 2; ++dy) {
@@ -176,11 +219,17 @@ __global__ __launch_bounds__(NW * 64) void pyramid_pool_kernel(float* __restrict
         up_coeff(x0 + dx, 1, w2, xa, xb, lxa, lxb);
         up_coeff(x0 + dx, 2, w4, xc, xd, lxc, lxd);
         const long long cell = (long long)(y0 + dy) * w + x0 + dx;
-        float4 a1;
+        float4 a1, a2, a3;
         if constexpr (MODE == 2) a1 = *reinterpret_cast<const float4*>(q1s + ((y0 + dy - by * 8) * 8 + (x0 + dx - bx * 8)) * QP + lane * 4);
         else a1 = ld4(q1 + cell * LBM_C);
-        const float4 a2 = bil(q2, w2, ya, yb, xa, xb, lya, lyb, lxa, lxb);
-        const float4 a3 = bil(q3, w4, yc, yd, xc, xd, lyc, lyd, lxc, lxd);
+        if constexpr (PATCH) {
+          // level 1: row y0 + dy reads patch rows (dy, dy + 1), column x0 + dx patch columns (dx, dx + 1)
+          a2 = bilv(p2[dy][dx], p2[dy][dx + 1], p2[dy + 1][dx], p2[dy + 1][dx + 1], lya, lyb, lxa, lxb);
+          a3 = bilv(p3[0][0], p3[0][1], p3[1][0], p3[1][1], lyc, lyd, lxc, lxd);
+        } else {
+          a2 = bil(q2, w2, ya, yb, xa, xb, lya, lyb, lxa, lxb);
+          a3 = bil(q3, w4, yc, yd, xc, xd, lyc, lyd, lxc, lxd);
+        }
         float4 t = make_float4(gelu_erf(a1.x + a2.x + a3.x), gelu_erf(a1.y + a2.y + a3.y), gelu_erf(a1.z + a2.z + a3.z),
                                gelu_erf(a1.w + a2.w + a3.w));
         if (ta.pos) {
@@ -239,6 +288,7 @@ int pyramid_pool(float* tokens, int B, int h, int w, hipStream_t stream, void* t
   return check_launch("pyramid_pool");
 }
 
+extern int g_tail_order;
 int encoder_tail(const float* q1, const float* q2, const float* q3, const float* pos, float* tokens, int B, int h, int w,
                  hipStream_t stream, void* toks, long long toks_plane) {
   LBM_REQUIRE(q1 && q2 && q3 && tokens && B > 0 && h % 8 == 0 && w % 8 == 0, "encoder_tail: bad arguments (grid %dx%d)", h, w);
@@ -249,11 +299,12 @@ int encoder_tail(const float* q1, const float* q2, const float* q3, const float*
   ProfScope prof("encoder_tail", stream, 0.0, 4.0 * LBM_C * B * ((double)P0 * (1.0 + 0.25 + 0.0625 + (pos ? 1.0 : 0.0)) + (double)L * (toks ? 2.0 : 1.0)));
   TailArgs ta{};
   ta.q1 = q1; ta.q2 = q2; ta.q3 = q3; ta.pos = pos;
-  hipLaunchKernelGGL(pyramid_pool_kernel<1>, dim3((unsigned)blocks), dim3(1024), 0, stream, tokens, B, h, w, L, toks, toks_plane, ta);
+  if (g_tail_order & 2) hipLaunchKernelGGL((pyramid_pool_kernel<1, 16, false>), dim3((unsigned)blocks), dim3(1024), 0, stream, tokens, B, h, w, L, toks, toks_plane, ta);
+  else hipLaunchKernelGGL((pyramid_pool_kernel<1, 16, true>), dim3((unsigned)blocks), dim3(1024), 0, stream, tokens, B, h, w, L, toks, toks_plane, ta);
   return check_launch("encoder_tail");
 }
 
-int g_tail_order = 1;   // debug key 24: 0 = workgroups of the fused encoder tail stream by stream
+int g_tail_order = 1;   // debug key 24: bit 0 = workgroups of the fused encoder tail stream-minor (0: stream by stream), bit 1 = cell-by-cell bilinear taps (the form before the patch)
 
 // encoder_tail with the finest level's 64 -> 256 product inside: f1 split planes [B, h*w, 64], W1 split [256, ldw1], b1 [256] or null
 int encoder_tail_fused(const void* f1, long long f1_plane, const void* w1h, const void* w1l, int ldw1, const float* b1, const float* q2,
@@ -271,9 +322,15 @@ int encoder_tail_fused(const void* f1, long long f1_plane, const void* w1h, cons
   TailArgs ta{};
   ta.q2 = q2; ta.q3 = q3; ta.pos = pos;
   ta.f1 = (const _Float16*)f1; ta.f1_plane = f1_plane; ta.w1h = (const _Float16*)w1h; ta.w1l = (const _Float16*)w1l; ta.ldw1 = ldw1; ta.b1 = b1; ta.inv = inv_norm;
-  ta.stream_minor = (g_tail_order && pos != nullptr && B >= 8) ? 1 : 0;
-  if (blocks >= 512) hipLaunchKernelGGL((pyramid_pool_kernel<2, 8>), dim3((unsigned)blocks), dim3(512), 0, stream, tokens, B, h, w, L, toks, toks_plane, ta);
-  else hipLaunchKernelGGL((pyramid_pool_kernel<2, 16>), dim3((unsigned)blocks), dim3(1024), 0, stream, tokens, B, h, w, L, toks, toks_plane, ta);
+  ta.stream_minor = ((g_tail_order & 1) && pos != nullptr && B >= 8) ? 1 : 0;
+  const bool patch = !(g_tail_order & 2);
+  if (blocks >= 512) {
+    if (patch) hipLaunchKernelGGL((pyramid_pool_kernel<2, 8, true>), dim3((unsigned)blocks), dim3(512), 0, stream, tokens, B, h, w, L, toks, toks_plane, ta);
+    else hipLaunchKernelGGL((pyramid_pool_kernel<2, 8, false>), dim3((unsigned)blocks), dim3(512), 0, stream, tokens, B, h, w, L, toks, toks_plane, ta);
+  } else {
+    if (patch) hipLaunchKernelGGL((pyramid_pool_kernel<2, 16, true>), dim3((unsigned)blocks), dim3(1024), 0, stream, tokens, B, h, w, L, toks, toks_plane, ta);
+    else hipLaunchKernelGGL((pyramid_pool_kernel<2, 16, false>), dim3((unsigned)blocks), dim3(1024), 0, stream, tokens, B, h, w, L, toks, toks_plane, ta);
+  }
   return check_launch("encoder_tail_fused");
 }
 

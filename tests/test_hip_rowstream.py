@@ -249,6 +249,45 @@ def test_encoder_tail_with_the_level0_product_inside_is_bit_identical(hip, B, h,
     assert torch.equal(outs[0][1].planes.view(torch.int16), outs[1][1].planes.view(torch.int16))
 
 
+@pytest.mark.parametrize("B,h,w,with_pos", [(1, 8, 8, True), (3, 16, 24, False), (8, 16, 8, True), (2, 96, 128, True)])
+def test_encoder_tail_patch_form_equals_the_cell_by_cell_taps(hip, B, h, w, with_pos):
+    """The encoder tail fetches, per 2 x 2 group of cells, one 3 x 3 patch of the half-resolution level and one 2 x 2 patch of the
+    quarter-resolution level (13 rows) where it used to fetch four bilinear taps per cell and level (32 rows); debug key 24 bit 1
+    selects the old form.  Tokens of all levels, split twin and row norms must be the same bits, borders included (grids of one
+    block, where every group touches an edge), for both entry points."""
+    lib = hip.load()
+    g = torch.Generator(device="cpu").manual_seed(7 * h + w + B)
+    P0 = h * w
+    L = P0 + P0 // 4 + P0 // 16 + P0 // 64
+    f1 = hip.split_tensor(torch.randn(B, h, w, 64, generator=g).cuda())
+    w1 = hip.SplitWeight((torch.randn(256, 64, generator=g) * 0.2).cuda())
+    b1 = torch.randn(256, generator=g).cuda()
+    q2 = torch.randn(B, P0 // 4, 256, generator=g).cuda()
+    q3 = torch.randn(B, P0 // 16, 256, generator=g).cuda()
+    pos = torch.randn(P0, 256, generator=g).cuda() if with_pos else None
+    q1 = hip.linear_ss(f1.reshape(-1, 64), w1, b1)[0]
+    outs = []
+    try:
+        for key in (3, 1):
+            lib.lbm_hip_debug_set(24, key)
+            for fused in (False, True):
+                tok = torch.zeros(B, L, 256, device="cuda")
+                toks = hip.SplitTensor((B, L, 256), "cuda")
+                inv = torch.zeros(B, L, device="cuda")
+                if fused:
+                    hip.encoder_tail_fused(f1, w1, b1, q2, q3, pos, tok, toks, h, w, inv)
+                else:
+                    hip.encoder_tail(q1, q2, q3, pos, tok, toks, h, w)
+                outs.append((tok, toks, inv))
+    finally:
+        lib.lbm_hip_debug_set(24, 1)
+    for other in outs[1:]:
+        assert torch.equal(outs[0][0].view(torch.int32), other[0].view(torch.int32))
+        assert torch.equal(outs[0][1].planes.view(torch.int16), other[1].planes.view(torch.int16))
+    assert torch.equal(outs[1][2].view(torch.int32), outs[3][2].view(torch.int32))
+    assert bool(torch.isfinite(outs[3][0]).all()) and float(outs[3][0].abs().max()) > 0
+
+
 def test_encoder_tail_row_norms_are_the_norm_kernels(hip):
     """The row factors lbm_hip_encoder_tail_fused leaves beside the tokens equal, bit for bit, what the step's own norm pass computes
     (lbm_hip_corr_maps writes them into its inv_norm argument)."""

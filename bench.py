@@ -377,7 +377,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
-                    help="default: c2 at --gpus 1, c3 (64 streams per GPU = BASELINE config 4) at --gpus > 1")
+                    help="default: c2 on every GPU (at --gpus > 1 the line also carries c3 per rank = BASELINE config 4 as workloads.c3_per_rank)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-extra-workloads", action="store_true", help="N = 1: skip the c3 / c5 entries of `workloads`")
@@ -400,7 +400,9 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks")
-    wname = args.workload or ("c2" if world == 1 else "c3")
+    # the same workload per GPU at every N (weak scaling: the N = 1 headline, BASELINE config 2, on every rank); BASELINE config 4
+    # (64 streams per GPU) rides along as workloads.c3_per_rank
+    wname = args.workload or "c2"
     wl = WORKLOADS[wname]
     if args.single_device:
         local = 0
@@ -475,25 +477,27 @@ def main():
         lat = lat_graph = None
         prof, extra = [], {}
         if dist is not None and args.workload is None and not args.no_extra_workloads:
-            # the N = 1 headline workload (c2: one stream x 1024 points) on every rank as well, bracketed by the same process-group
-            # barrier and reduced with MAX over ranks, so that a scaling ratio can be formed against the N = 1 line's `value` (c2 / c2)
-            # as well as against its `workloads.c3` (c3 / c3: BASELINE config 4, the headline of this line)
-            e2 = measure_throughput("c2", args.steps, args.warmup, rank, device, barrier, profile=False, preset=args.preset)
-            pf2 = e2["value"] * e2["ms_per_step"] / 1e3 * world            # point-frames per step, all ranks
-            e2["ms_per_step"] = 1e3 * max_over_ranks(e2["ms_per_step"] / 1e3, cdev)
-            e2["frame_pipeline"]["ms_per_step"] = 1e3 * max_over_ranks(e2["frame_pipeline"]["ms_per_step"] / 1e3, cdev)
-            e2["value"] = pf2 / (e2["ms_per_step"] / 1e3)
-            e2["frame_pipeline"]["value"] = pf2 / (e2["frame_pipeline"]["ms_per_step"] / 1e3)
-            e2["frame_pipeline"]["bit_identical"] = max_over_ranks(0.0 if e2["frame_pipeline"]["bit_identical"] else 1.0, cdev) == 0.0   # on EVERY rank
-            e2["serial_frames"] = {"ms_per_step": e2["ms_per_step"], "value": e2["value"]}
-            if e2["frame_pipeline"]["bit_identical"] and e2["frame_pipeline"]["value"] > e2["value"]:      # the headline rule of the N = 1 line
-                e2["ms_per_step"], e2["value"], e2["headline_mode"] = e2["frame_pipeline"]["ms_per_step"], e2["frame_pipeline"]["value"], "frame_pipeline"
-            else:
-                e2["headline_mode"] = "serial_frames"
-            e2["aggregate_over_ranks"] = world
-            for key in ("roofline", "kernels", "step_algorithmic_TFLOPs", "step_frac_of_f16_mfma_peak"):
-                e2.pop(key, None)
-            extra["c2_per_rank"] = e2
+            # BASELINE config 4 (64 streams x 256 points per GPU: 512 streams at N = 8) on every rank as well, bracketed by the same
+            # process-group barrier and reduced with MAX over ranks: its scaling ratio is formed against the N = 1 line's
+            # `workloads.c3` (c3 / c3), the headline's against that line's `value` (c2 / c2: the same per-GPU work at every N)
+            def per_rank_entry(name, steps):
+                e2 = measure_throughput(name, steps, min(args.warmup, 4), rank, device, barrier, profile=False, preset=args.preset)
+                pf2 = e2["value"] * e2["ms_per_step"] / 1e3 * world            # point-frames per step, all ranks
+                e2["ms_per_step"] = 1e3 * max_over_ranks(e2["ms_per_step"] / 1e3, cdev)
+                e2["frame_pipeline"]["ms_per_step"] = 1e3 * max_over_ranks(e2["frame_pipeline"]["ms_per_step"] / 1e3, cdev)
+                e2["value"] = pf2 / (e2["ms_per_step"] / 1e3)
+                e2["frame_pipeline"]["value"] = pf2 / (e2["frame_pipeline"]["ms_per_step"] / 1e3)
+                e2["frame_pipeline"]["bit_identical"] = max_over_ranks(0.0 if e2["frame_pipeline"]["bit_identical"] else 1.0, cdev) == 0.0   # on EVERY rank
+                e2["serial_frames"] = {"ms_per_step": e2["ms_per_step"], "value": e2["value"]}
+                if e2["frame_pipeline"]["bit_identical"] and e2["frame_pipeline"]["value"] > e2["value"]:      # the headline rule of the N = 1 line
+                    e2["ms_per_step"], e2["value"], e2["headline_mode"] = e2["frame_pipeline"]["ms_per_step"], e2["frame_pipeline"]["value"], "frame_pipeline"
+                else:
+                    e2["headline_mode"] = "serial_frames"
+                e2["aggregate_over_ranks"] = world
+                for key in ("roofline", "kernels", "step_algorithmic_TFLOPs", "step_frac_of_f16_mfma_peak"):
+                    e2.pop(key, None)
+                return e2
+            extra["c3_per_rank"] = per_rank_entry("c3", min(args.steps, 20))
         nprof = min(args.steps, 20)
         if world == 1:
             # p50 per-frame latency: each (serial) frame synchronised on its own; and the same with the frame step replayed as a
@@ -556,8 +560,8 @@ def main():
             line["world_size"] = dist.get_world_size()
             line["ranks"] = ranks
             line["gathered_records"] = list(gathered.shape)
-            line["scaling_base"] = ("per-GPU work is fixed (weak scaling): divide `value` by N x the N = 1 line's workloads.c3.frame_pipeline.value "
-                                    "(same workload per GPU; the N = 1 headline itself is c2), or workloads.c2_per_rank.value by N x that line's value")
+            line["scaling_base"] = ("per-GPU work is fixed (weak scaling): divide `value` by N x the N = 1 line's `value` (c2 on every GPU), and "
+                                    "workloads.c3_per_rank.value (BASELINE config 4: 64 streams per GPU) by N x that line's workloads.c3 figure of the same headline_mode")
         # a scaling curve needs real GPUs behind every rank: a single-device / gloo rehearsal is not one
         line["scaling_measured"] = bool(world > 1 and args.backend == "nccl" and not args.single_device)
         if not line["scaling_measured"]:

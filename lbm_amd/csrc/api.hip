@@ -872,6 +872,7 @@ int lbm_hip_debug_set(int32_t key, int32_t value) {
   // (`make tuning`, -DLBM_TUNING): the product library refuses them instead of silently doing nothing.
   const bool ablation = (key == 14 || key == 16 || key == 20 || key == 23) ? value != 0
                         : key == 18                           ? (value & 255) != 0
+                        : key == 24                           ? (value & ~15) != 0
                         : key == 2                            ? (value & ~0x7f0) != 0
                                                               : false;
   if (ablation) {

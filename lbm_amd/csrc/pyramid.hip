@@ -51,6 +51,7 @@ struct TailArgs {
   const float* b1;
   float* inv;           // [B, L] or null: 1 / max(|row|, 1e-12) of every token row written here (what corr_maps would compute)
   int stream_minor;     // workgroup order: 1 = the same 8 x 8 block of every stream back to back (they share its rows of `pos`), 0 = stream by stream
+  int dbg;              // tuning build only (debug key 24, bits 4..): 16 = no level-0 product, 32 = no q2 / q3 / pos loads, 64 = no stores, 128 = no GELU
 };
 
 // F.normalize's factor for one 256-channel row held by a wave (lane = 4 channels); every rounding spelled out: the encoder tail and
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(NW * 64) void pyramid_pool_kernel(float* __restrict
    half8 bh[4], bl[4];
    float bv = 0.f;
 #pragma unroll 1
-   for (int gi = 0; gi < GPW; ++gi) {
+   for (int gi = 0; gi < (LBM_ABL(ta.dbg & 16) ? 0 : GPW); ++gi) {
     const int q = wv + gi * NW;
     const int r = lane & 31, hh = lane >> 5, rb = q >> 3, cbk = q & 7;
     const int c = 32 * rb + r;                                          // cell of the 8 x 8 block, row-major
@@ -141,6 +142,7 @@ __global__ __launch_bounds__(NW * 64) void pyramid_pool_kernel(float* __restrict
   auto add = [](float4 a, const float4 c) { a.x += c.x; a.y += c.y; a.z += c.z; a.w += c.w; return a; };
   auto mul = [](const float4 a, float f) { return make_float4(a.x * f, a.y * f, a.z * f, a.w * f); };
   auto put = [&](long long cell, const float4 o) {
+    if (LBM_ABL(ta.dbg & 64) && o.x != 12345.678f) return;
     st4(base + cell * LBM_C, o);
     if (toks) st4_split(toks, toks_plane, sbase + cell * LBM_C, o);
     if constexpr (TAIL) {
@@ -180,7 +182,13 @@ __global__ __launch_bounds__(NW * 64) void pyramid_pool_kernel(float* __restrict
     };
     // PATCH: every row of the group requested before anything is used
     float4 p2[3][3], p3[2][2];
-    if constexpr (PATCH) {
+    if (LBM_ABL(ta.dbg & 32)) {
+#pragma unroll
+      for (int u = 0; u < 3; ++u)
+#pragma unroll
+        for (int v2 = 0; v2 < 3; ++v2) p2[u][v2] = make_float4(0.1f * lane, 0.2f, 0.3f, 0.4f);
+      p3[0][0] = p3[0][1] = p3[1][0] = p3[1][1] = make_float4(0.5f, 0.1f * lane, 0.7f, 0.8f);
+    } else if constexpr (PATCH) {
       const int iy = y0 >> 1, ix = x0 >> 1;
       const int ry[3] = {max(iy - 1, 0), iy, min(iy + 1, h2 - 1)};
       const int rx[3] = {max(ix - 1, 0), ix, min(ix + 1, w2 - 1)};
@@ -230,13 +238,14 @@ __global__ __launch_bounds__(NW * 64) void pyramid_pool_kernel(float* __restrict
           a2 = bil(q2, w2, ya, yb, xa, xb, lya, lyb, lxa, lxb);
           a3 = bil(q3, w4, yc, yd, xc, xd, lyc, lyd, lxc, lxd);
         }
-        float4 t = make_float4(gelu_erf(a1.x + a2.x + a3.x), gelu_erf(a1.y + a2.y + a3.y), gelu_erf(a1.z + a2.z + a3.z),
-                               gelu_erf(a1.w + a2.w + a3.w));
-        if (ta.pos) {
+        float4 t = make_float4(a1.x + a2.x + a3.x, a1.y + a2.y + a3.y, a1.z + a2.z + a3.z, a1.w + a2.w + a3.w);
+        if (!(LBM_ABL(ta.dbg & 128))) t = make_float4(gelu_erf(t.x), gelu_erf(t.y), gelu_erf(t.z), gelu_erf(t.w));
+        if (ta.pos && !(LBM_ABL(ta.dbg & 32))) {
           const float4 p = ld4(ta.pos + cell * LBM_C + lane * 4);
           t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w;
         }
         v[dy][dx] = t;
+        if (LBM_ABL(ta.dbg & 64) && t.x != 12345.678f) continue;
         st4(base + cell * LBM_C, t);
         if (ta.inv) {
           const float sn = row_inv_norm(t);
@@ -245,7 +254,7 @@ __global__ __launch_bounds__(NW * 64) void pyramid_pool_kernel(float* __restrict
       }
     }
   }
-  if (toks) {
+  if (toks && !(LBM_ABL(ta.dbg & 64) && v[0][0].x != 12345.678f)) {
 #pragma unroll
     for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
@@ -323,6 +332,7 @@ int encoder_tail_fused(const void* f1, long long f1_plane, const void* w1h, cons
   ta.q2 = q2; ta.q3 = q3; ta.pos = pos;
   ta.f1 = (const _Float16*)f1; ta.f1_plane = f1_plane; ta.w1h = (const _Float16*)w1h; ta.w1l = (const _Float16*)w1l; ta.ldw1 = ldw1; ta.b1 = b1; ta.inv = inv_norm;
   ta.stream_minor = ((g_tail_order & 1) && pos != nullptr && B >= 8) ? 1 : 0;
+  ta.dbg = LBM_ABL(g_tail_order & ~15);
   const bool patch = !(g_tail_order & 2);
   if (blocks >= 512) {
     if (patch) hipLaunchKernelGGL((pyramid_pool_kernel<2, 8, true>), dim3((unsigned)blocks), dim3(512), 0, stream, tokens, B, h, w, L, toks, toks_plane, ta);

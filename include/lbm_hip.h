@@ -427,7 +427,7 @@ int lbm_hip_profile_begin(void);
 int lbm_hip_profile_end(lbm_hip_profile_entry* out, int32_t cap);
 
 /* tuning / debugging knobs (process-wide; 0 restores the default unless noted).  None changes results beyond the last bit except
- * the reproducer variants of key 9 and the timing-only ablation switches (keys 14 / 16 / 18 bits 0-7 / 20 and bits 12.. of key 2:
+ * the reproducer variants of key 9 and the timing-only ablation switches (keys 14 / 16 / 18 bits 0-7 / 20 / 23, bits 4.. of key 24 and bits 12.. of key 2:
  * results are WRONG when set).  The ablation code exists only in the tuning build (`make -C lbm_amd/csrc tuning`, -DLBM_TUNING ->
  * liblbm_hip_tuning.so, see lbm_hip_tuning_build): the product library refuses those values with an error.
  *   1  force the split-GEMM tiling (1..23, gemm16.hip)          2  split-GEMM flags (256 = never / 512 = always the row-streaming
@@ -450,7 +450,9 @@ int lbm_hip_profile_end(lbm_hip_profile_entry* out, int32_t cap);
  *  22  deformable-sampling kernels (bit mask, default 3): 1 = LDS-window kernel for the k = 9 / 4 lattice launches, 2 = tap-table
  *      kernel for the k = 1 launches; 0 = the direct gather everywhere (bit-identical rows, the A/B of DESIGN.md section 5)
  *  23  msda_window timing-only ablation bits (tuning build): 1 no tap table, 2 no staging, 4 no accumulation, 8 no prologue reductions
- *  24  encoder tail workgroup order: 1 (default) the same 8 x 8 block of every stream back to back, 0 stream by stream
+ *  24  encoder tail (bit mask, default 1): bit 0 = workgroup order, the same 8 x 8 block of every stream back to back (0: stream by
+ *      stream); bit 1 = cell-by-cell bilinear taps instead of one patch per 2 x 2 group (bit-identical tokens, the A/B of DESIGN.md
+ *      section 8); bits 4.. timing-only ablation (tuning build): 16 no level-0 product, 32 no tap / pos loads, 64 no stores, 128 no GELU
  *  25  gemm_rs LDS ring: 3 (default) or 4 stages (steps fetched two / three ahead); bit-identical, measured equal             */
 int lbm_hip_debug_set(int32_t key, int32_t value);
 /* The knobs that currently differ from their defaults (what a measurement must state beside its figure; bench.py prints them

@@ -427,7 +427,7 @@ int lbm_hip_profile_begin(void);
 int lbm_hip_profile_end(lbm_hip_profile_entry* out, int32_t cap);
 
 /* tuning / debugging knobs (process-wide; 0 restores the default unless noted).  None changes results beyond the last bit except
- * the reproducer variants of key 9 and the timing-only ablation switches (keys 14 / 16 / 18 bits 0-7 / 20 / 23, bits 4.. of key 24 and bits 12.. of key 2:
+ * the reproducer variants of key 9 and the timing-only ablation switches (keys 14 / 16 / 18 bits 0-7 / 20 / 23, bits 4.. of key 24, bits 0-7 of key 26 and bits 12.. of key 2:
  * results are WRONG when set).  The ablation code exists only in the tuning build (`make -C lbm_amd/csrc tuning`, -DLBM_TUNING ->
  * liblbm_hip_tuning.so, see lbm_hip_tuning_build): the product library refuses those values with an error.
  *   1  force the split-GEMM tiling (1..23, gemm16.hip)          2  split-GEMM flags (256 = never / 512 = always the row-streaming
@@ -453,7 +453,10 @@ int lbm_hip_profile_end(lbm_hip_profile_entry* out, int32_t cap);
  *  24  encoder tail (bit mask, default 1): bit 0 = workgroup order, the same 8 x 8 block of every stream back to back (0: stream by
  *      stream); bit 1 = cell-by-cell bilinear taps instead of one patch per 2 x 2 group (bit-identical tokens, the A/B of DESIGN.md
  *      section 8); bits 4.. timing-only ablation (tuning build): 16 no level-0 product, 32 no tap / pos loads, 64 no stores, 128 no GELU
- *  25  gemm_rs LDS ring: 3 (default) or 4 stages (steps fetched two / three ahead); bit-identical, measured equal             */
+ *  25  gemm_rs LDS ring: 3 (default) or 4 stages (steps fetched two / three ahead); bit-identical, measured equal
+ *  26  conv_patch (3 x 3 convolutions 128 -> 128 / 256 -> 256 of many frames; key 4: 21 = never, 22 = whenever the shape admits it):
+ *      bits 8.. = pixels per tile (192 / 256, 0 = chosen by the launcher), bits 0-7 timing-only ablation (tuning build): 1 no patch DMA
+ *      after the first, 2 no weight DMA after the prologue, 4 no MFMAs, 8 no epilogue                                                   */
 int lbm_hip_debug_set(int32_t key, int32_t value);
 /* The knobs that currently differ from their defaults (what a measurement must state beside its figure; bench.py prints them
  * in `config.knobs` and refuses a headline when any is set): writes up to `cap` (key, value) pairs, returns how many there are. */

@@ -176,6 +176,8 @@ extern int g_msda_window;           // msda.hip (debug key 22)
 extern int g_msda_dbg;              // msda.hip (debug key 23)
 extern int g_tail_order;            // pyramid.hip (debug key 24)
 extern int g_rs_ring;               // gemm_rs.hip (debug key 25)
+extern int g_conv_patch_dbg;        // conv_patch.hip (debug key 26, bits 0-7)
+extern int g_conv_patch_tile;       // conv_patch.hip (debug key 26, bits 8..)
 static int g_head_pair = 1;         // tuning (debug key 17): 0 = offset and visibility heads as two separate chains
 static int g_ffn_rows_mode = 0;     // tuning (debug key 15): 0 = many-rows fused feed-forward from g_ffn_fused_rows + 1 rows on, 1 = never, 2 = for any row count
 static int g_ffn_fused_rows = 2048; // tuning (debug key 7): most rows for which the feed-forward runs as one fused launch (0: never)
@@ -871,6 +873,7 @@ int lbm_hip_debug_set(int32_t key, int32_t value) {
   // The timing-only ablation switches (results are wrong when set) are compiled into the tuning build only
   // (`make tuning`, -DLBM_TUNING): the product library refuses them instead of silently doing nothing.
   const bool ablation = (key == 14 || key == 16 || key == 20 || key == 23) ? value != 0
+                        : key == 26                           ? (value & 255) != 0
                         : key == 18                           ? (value & 255) != 0
                         : key == 24                           ? (value & ~15) != 0
                         : key == 2                            ? (value & ~0x7f0) != 0
@@ -954,6 +957,11 @@ int lbm_hip_debug_set(int32_t key, int32_t value) {
   }
   if (key == 24) {
     lbm::g_tail_order = value;
+    return 0;
+  }
+  if (key == 26) {
+    lbm::g_conv_patch_dbg = value & 255;
+    lbm::g_conv_patch_tile = value >> 8;
     return 0;
   }
   if (key == 25) {

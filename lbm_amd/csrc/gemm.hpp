@@ -112,6 +112,10 @@ int conv2d_nhwc_ss(const ConvSSArgs& c, hipStream_t stream);
 // 3 x 3 / stride 1 / 64 -> 64 channels over many pixels: weights stationary, image patches streamed (conv_rs.hip); bit-identical
 bool conv64_rows_ok(const ConvSSArgs& c);
 int conv64_rows(const ConvSSArgs& c, hipStream_t stream);
+// 3 x 3 / stride 1 / 128 -> 128 or 256 -> 256 channels on 64- / 32-pixel-wide maps, many pixels: the input patch of a 256-pixel tile stays
+// in LDS for all nine taps, only the weights stream (conv_patch.hip); same products, summed channel chunk by channel chunk
+bool conv_patch_ok(const ConvSSArgs& c);
+int conv_patch(const ConvSSArgs& c, hipStream_t stream);
 // stem_rs.hip: 7 x 7 stride-2 convolution (3 + 1 zero channels -> 64) + ReLU + 3 x 3 stride-2 max-pooling in one launch
 bool stem_pool_ok(int H, int W, int ldw);
 int stem_pool(const void* X, long long x_plane, const void* Wh, const void* Wl, int ldw, const float* bias, float* Y, void* Ys,

@@ -970,7 +970,10 @@ int conv2d_nhwc_ss(const ConvSSArgs& c, hipStream_t stream) {
   d.zeros = c.zeros; d.dbg = g_dbg16;
   // few output pixels (one stream, deep layers): split K over gridDim.z into fp32 slabs and reduce them afterwards
   // layer1-shaped convolutions over many pixels: the patch-streaming kernel (debug key 4: 15 = never, 16 = whenever the shape admits it)
-  if (g_force_conv != 15 && conv64_rows_ok(c) && (g_force_conv == 16 || g_force_conv == 0)) return conv64_rows(c, stream);
+  if (g_force_conv != 15 && conv64_rows_ok(c) && (g_force_conv == 16 || g_force_conv == 0 || g_force_conv >= 21)) return conv64_rows(c, stream);
+  // layer2 / layer3-shaped convolutions over many pixels: the patch-resident kernel (debug key 4: 21 = never, 22 = whenever the shape admits it)
+  if (g_force_conv != 21 && conv_patch_ok(c) && (g_force_conv == 22 || ((g_force_conv == 0 || g_force_conv == 16) && (M / 256) * (c.Cout / 128) >= 256)))
+    return conv_patch(c, stream);
   const int nk = K / 32;
   const long long big = ((M + 127) / 128) * ((c.Cout + 127) / 128);
   const long long mid = ((M + 63) / 64) * ((c.Cout + 63) / 64);

@@ -302,7 +302,9 @@ __global__ __launch_bounds__(64 * HPW) void msda_window_kernel(MsdaArgs a) {
     if (LBM_ABL(a.dbg & 1))                       // (ablation: a valid, constant tap table -- slot 0, weight 0)
       for (int i = lane; i < NI * 4; i += 64) meta[i] = make_int2(0, 0);
     // 2. the taps, once: lane = (reference cell, sample)
-#pragma unroll
+    // (not unrolled: with both passes of k = 9 interleaved the kernel needs 184 registers -- two waves per SIMD; 166 leave room for
+    // a third: 729 -> 719 us on clustered cells at C3 size)
+#pragma unroll 1
     for (int ps = 0; ps < (LBM_ABL(a.dbg & 1) ? 0 : NPASS); ++ps) {
       const int item = ps * 64 + lane;
       if (item < NI) {

@@ -182,6 +182,50 @@ def test_patch_streaming_convolution_is_bit_identical_to_the_tiled_one(hip, B, H
         assert torch.equal(s0.planes.view(torch.int16), s1.planes.view(torch.int16))
 
 
+@pytest.mark.parametrize("B,H,W,C,tile", [(2, 8, 64, 128, 256), (3, 6, 64, 128, 192), (1, 12, 64, 128, 0), (2, 8, 32, 256, 256), (1, 12, 32, 256, 192),
+                                          (3, 24, 32, 256, 0), (1, 4, 64, 256, 0), (5, 6, 32, 128, 0)])
+@pytest.mark.parametrize("relu,use_res,f32,split", [(True, False, False, True), (True, True, True, True), (False, True, True, False)])
+def test_patch_resident_convolution_matches_the_tiled_one(hip, B, H, W, C, tile, relu, use_res, f32, split):
+    """conv_patch_kernel (3 x 3, stride 1, C -> C with C = 128 / 256 on 64- / 32-pixel-wide maps: the input patch of a 256- or 192-pixel tile
+    stays in LDS for all nine taps, weights stream; debug key 4 = 22, tile forced by key 26 >> 8) against the tiled implicit GEMM (key 4 = 21)
+    and against float64: the same products summed channel chunk by channel chunk instead of tap by tap, so agreement is to fp32
+    rounding -- image borders (zero padding above / below / left / right of every tile), tiles at image boundaries of a batch, one to
+    several tiles per image, every output combination."""
+    lib = hip.load()
+    g = torch.Generator(device="cpu").manual_seed(B * 100 + H + C)
+    x = torch.randn(B, H, W, C, generator=g).cuda()
+    w4 = torch.randn(C, C, 3, 3, generator=g) * 0.03
+    w = hip.SplitWeight(w4.permute(0, 2, 3, 1).reshape(C, 9 * C).contiguous().cuda())
+    b = torch.randn(C, generator=g).cuda()
+    res = torch.randn(B, H, W, C, generator=g).cuda() if use_res else None
+    xs = _split(hip, x)
+    outs = {}
+    try:
+        for mode in (21, 22):
+            lib.lbm_hip_debug_set(4, mode)
+            lib.lbm_hip_debug_set(26, tile << 8)
+            hip.profile_begin()
+            outs[mode] = hip.conv2d_nhwc_ss(xs, w, b, 3, 1, 1, relu, res, f32, split)
+            names = {p["name"] for p in hip.profile_end()}
+            assert ("conv_patch" in names) == (mode == 22), names
+    finally:
+        lib.lbm_hip_debug_set(4, 0)
+        lib.lbm_hip_debug_set(26, 0)
+    want = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double().cpu(), w4.double(), b.double().cpu(), padding=1).permute(0, 2, 3, 1)
+    if use_res:
+        want = want + res.double().cpu()
+    if relu:
+        want = torch.relu(want)
+    tol = 4e-6 * max(1.0, float(want.abs().max()))
+    (y0, s0), (y1, s1) = outs[21], outs[22]
+    if f32:
+        assert float((y1.double().cpu() - want).abs().max()) < tol
+        assert float((y1 - y0).abs().max()) < tol
+    if split:
+        assert float((s1.float().double().cpu() - want).abs().max()) < tol
+        assert float((s1.float() - s0.float()).abs().max()) < tol
+
+
 @pytest.mark.parametrize("B,H,W", [(1, 8, 8), (2, 36, 124), (1, 96, 128), (3, 64, 256), (1, 384, 512)])
 def test_fused_stem_matches_convolution_relu_maxpool(hip, B, H, W):
     """stem_pool (7 x 7 / 2 convolution + ReLU + 3 x 3 / 2 max-pooling in one launch, stem_rs.hip) against the two separate kernels

@@ -36,6 +36,7 @@ struct ConvPatchDev {
   long long ys_plane;
   const _Float16* zeros;
   int H, Cin, Cout, relu, cin_log2;
+  int items;   // (tiles of pixels) x (blocks of 128 output channels), output-channel block fastest
   int dbg;   // tuning (timing only, debug key 26): 1 no patch DMA after the first, 2 no weight DMA after the prologue, 4 no MFMAs, 8 no epilogue
 };
 
@@ -54,177 +55,234 @@ __device__ __forceinline__ void cp_wait(int n) {      // n wave-uniform, 0..5
 
 // WO: image width (64 / 32); TR: image rows per tile; the tile's BM = TR * WO pixels are dealt to BM / 64 rows of waves (64 pixels
 // each, two 32-pixel MFMA blocks), four waves (32 output channels each) per row: 16 waves at BM = 256, 12 at BM = 192.
+//
+// PERSISTENT: a workgroup walks items (tile of pixels x block of 128 output channels) w, w + G, ... so that nothing of a tile's start
+// and end is paid per tile: the first patch of the next item is fetched during the last channel chunk of the current one (its buffer is
+// free by then), its first two weight chunks right behind the main loop.  ROLES: every wave multiplies, but only the LOWER half of the
+// waves issue DMA and only the UPPER half run the epilogue's residual loads and output stores -- vector memory operations of a wave
+// retire in issue order, so a wave that both stored and fetched would have to see its stores complete before its next fetch could be
+// waited for; this way the stores of a tile drain behind the next tile's multiplication.  The epilogue passes the tile through LDS in
+// slices of 64 rows (one row of waves), which fit the patch buffer that is idle at that moment.
 template <int WO, int TR>
 __global__ __launch_bounds__(TR * WO * 4) void conv_patch_kernel(ConvPatchDev a) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int BM = TR * WO;
   constexpr int NW = BM / 16;                  // waves
+  constexpr int NWM = NW / 4;                  // rows of waves
+  constexpr int ND = NW / 2;                   // DMA waves (0 .. ND - 1); the others store
   constexpr int PW = WO + 2, PROWS = TR + 2;
   constexpr int NPIX = PROWS * PW;             // patch pixels per plane
   constexpr int NPP = (NPIX + 15) / 16;        // 1-KiB DMA pieces per plane (16 pixels each)
   constexpr int PLANE_P = NPP * 1024;
   constexpr int PATCHB = 2 * PLANE_P;          // one patch buffer: [hi plane][lo plane]
   constexpr int NPC = 2 * NPP;                 // pieces per patch
-  constexpr int NPW = (NPC + NW - 1) / NW;     // most patch pieces per wave
-  constexpr int NBW = (16 + NW - 1) / NW;      // most weight pieces per wave and chunk
+  constexpr int NPW = (NPC + ND - 1) / ND;     // most patch pieces per DMA wave
+  constexpr int NBW = (16 + ND - 1) / ND;      // most weight pieces per DMA wave and chunk
   constexpr int BSTAGE = 16384;                // weights of one chunk: [hi: 128 rows x 64 B][lo]
   constexpr int NB = 3;
-  constexpr int OFF_B = 2 * PATCHB;
-  constexpr int TP = 132;                      // pitch (floats) of the output tile staged in the epilogue
-  constexpr int LDS_BYTES = OFF_B + NB * BSTAGE > BM * TP * 4 ? OFF_B + NB * BSTAGE : BM * TP * 4;
-  static_assert(BM % 64 == 0 && LDS_BYTES <= 160 * 1024, "tile / LDS budget");
-  static_assert(NPW <= 4 && NBW <= 2, "wait table: at most 2 + 2 operations in flight behind the awaited weights");
+  // LDS: [patch 0][weights 0][weights 1][patch 1][weights 2]; the epilogue's 64-row slice lives in patch 1
+  constexpr int OFF_P0 = 0, OFF_B0 = PATCHB, OFF_P1 = PATCHB + 2 * BSTAGE, OFF_B2 = OFF_P1 + PATCHB;
+  constexpr int LDS_BYTES = OFF_B2 + BSTAGE;
+  constexpr int TP = 132;                      // pitch (floats) of the staged slice
+  static_assert(BM % 64 == 0 && LDS_BYTES <= 160 * 1024 && 64 * TP * 4 <= PATCHB, "tile / LDS budget");
+  static_assert(NPW <= 9 && NBW <= 3, "one patch piece per chunk; wait table");
   __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   const int r = lane & 31, h = lane >> 5;
-  const int n0 = blockIdx.x * 128;
-  const long long m0 = (long long)blockIdx.y * BM;
+  const bool dma_wave = wave < ND;
   const int hw = a.H * WO;
-  const int b = (int)(m0 / hw);
-  const int y0 = (int)(m0 - (long long)b * hw) / WO;          // first image row of the tile (a multiple of TR)
   const int NCC = a.Cin >> 5, NQ = NCC * 9;
+  const int ntn = a.Cout >> 7;
+  const int G = gridDim.x;
 
-  // ---- patch DMA: wave w fetches pieces w, w + NW, ... , ONE per chunk during the first taps of the channel chunk before; per lane
-  // an element offset into the plane (or -1: zeros) ----
-  const int npw = (NPC - wave + NW - 1) / NW;                 // this wave's pieces (wave-uniform)
-  auto mk_poff = [&](int i) __attribute__((always_inline)) {
-    const int pc = wave + NW * i;
+  auto sync_lds = [&]() __attribute__((always_inline)) {     // LDS-only workgroup barrier: vector memory stays in flight
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  auto stage_w = [&](int st) __attribute__((always_inline)) { return lds + (st == 2 ? OFF_B2 : OFF_B0 + st * BSTAGE); };
+  auto patch_buf = [&](int cc) __attribute__((always_inline)) { return lds + ((cc & 1) ? OFF_P1 : OFF_P0); };
+
+  // ---- patch DMA (DMA waves): wave w fetches pieces w, w + ND, ..., one per chunk; the source of a piece is worked out when it is
+  // issued (element offset into the plane, or the zero page for pixels outside the image) ----
+  const int npw = dma_wave ? (NPC - wave + ND - 1) / ND : 0;  // this wave's pieces (wave-uniform)
+  auto issue_patch_piece = [&](int b, int y0, int cc, int i) __attribute__((always_inline)) {      // i wave-uniform, < npw
+    const int pc = wave + ND * i;
     const int pp = pc < NPP ? pc : pc - NPP;
     const int pixel = pp * 16 + (lane >> 2);
     const int chunk = (lane & 3) ^ ((pixel >> 2) & 3);
     const int row = pixel / PW, px = pixel - row * PW;
     const int y = y0 - 1 + row, x = px - 1;
-    const bool ok = pc < NPC && pixel < NPIX && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)WO;
-    return ok ? (int)((((long long)b * a.H + y) * WO + x) << a.cin_log2) + chunk * 8 : -1;
-  };
-  // (four scalars, not an array: indexed by a run-time piece number an array ends up in scratch / LDS)
-  const int po0 = mk_poff(0), po1 = mk_poff(1), po2 = NPW > 2 ? mk_poff(2) : -1, po3 = NPW > 3 ? mk_poff(3) : -1;
-  auto issue_patch_piece = [&](int cc, int i) __attribute__((always_inline)) {      // i wave-uniform, < npw
-    unsigned char* buf = lds + (cc & 1) * PATCHB;
-    const int pc = wave + NW * i;
-    const int po = i == 0 ? po0 : i == 1 ? po1 : i == 2 ? po2 : po3;
+    const bool ok = pixel < NPIX && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)WO;
     const _Float16* plane = a.X + (pc < NPP ? 0 : a.x_plane);
-    const _Float16* g = po >= 0 ? plane + po + cc * 32 : a.zeros;
-    __builtin_amdgcn_global_load_lds(g, (lds_ptr_cp)(buf + pc * 1024), 16, 0, 0);
+    const _Float16* g = ok ? plane + (((long long)b * a.H + y) * WO + x) * a.Cin + chunk * 8 + cc * 32 : a.zeros;
+    __builtin_amdgcn_global_load_lds(g, (lds_ptr_cp)(patch_buf(cc) + pc * 1024), 16, 0, 0);
   };
-  // ---- weight DMA: pieces w (and w + NW) of the chunk's 16 (16 rows of one plane each) ----
-  const int nbw = (16 - wave + NW - 1) / NW;
-  const _Float16* wsrc[NBW];
+  // ---- weight DMA (DMA waves): pieces w, w + ND, ... of the chunk's 16 (16 rows of one plane each) ----
+  const int nbw = dma_wave ? (16 - wave + ND - 1) / ND : 0;
+  long long woff[NBW];                         // element offset of this lane's 16 bytes inside the weights, without n0 and k
 #pragma unroll
   for (int i = 0; i < NBW; ++i) {
-    const int pc = (wave + NW * i) & 15;
+    const int pc = (wave + ND * i) & 15;
     const int rowb = (pc & 7) * 16 + (lane >> 2);
     const int chunk = (lane & 3) ^ ((rowb >> 2) & 3);
-    wsrc[i] = a.Wh + (pc >> 3) * a.w_plane + (long long)(n0 + rowb) * a.ldw + chunk * 8;
+    woff[i] = (pc >> 3) * a.w_plane + (long long)rowb * a.ldw + chunk * 8;
   }
-  auto issue_w = [&](int q, int koff) __attribute__((always_inline)) {
+  auto issue_w = [&](int n0, int st, int koff) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < NBW; ++i)
       if (i < nbw)
-        __builtin_amdgcn_global_load_lds(wsrc[i] + koff, (lds_ptr_cp)(lds + OFF_B + (q % NB) * BSTAGE + (wave + NW * i) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(a.Wh + woff[i] + (long long)n0 * a.ldw + koff, (lds_ptr_cp)(stage_w(st) + (wave + ND * i) * 1024), 16, 0, 0);
   };
 
   // ---- fragment offsets ----
   int p0[2];                                   // base patch pixel of block i for this lane (tap (0, 0))
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    constexpr int dummy = 0; (void)dummy;
     const int t0 = 64 * wm + 32 * i;           // first tile pixel of the block, raster order
     p0[i] = (t0 / WO) * PW + (t0 % WO) + r;
   }
   const int rowB = wn * 32 + r;
   const int offB = rowB * 64 + ((h ^ ((rowB >> 2) & 3)) << 4);
 
-  f32x16 acc[2], acx[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[i][e] = acx[i][e] = 0.f;
+  auto item_of = [&](int it, int& b, int& y0, int& n0, long long& m0) __attribute__((always_inline)) {
+    const int tm = it / ntn;
+    n0 = (it - tm * ntn) * 128;
+    m0 = (long long)tm * BM;
+    b = (int)(m0 / hw);
+    y0 = (int)(m0 - (long long)b * hw) / WO;   // first image row of the tile (a multiple of TR)
+  };
 
-  // k offset of chunk q = cc * 9 + tap inside a weight row: tap * Cin + cc * 32
-  for (int i = 0; i < npw; ++i) issue_patch_piece(0, i);
-  issue_w(0, 0);
-  issue_w(1, a.Cin);                           // (tap 1, cc 0)
+  int it = blockIdx.x;
+  if (it >= a.items) return;
+  int b, y0, n0;
+  long long m0;
+  item_of(it, b, y0, n0, m0);
+  if (dma_wave) {
+    for (int i = 0; i < npw; ++i) issue_patch_piece(b, y0, 0, i);
+    issue_w(n0, 0, 0);
+    issue_w(n0, 1, a.Cin);                     // (tap 1, cc 0)
+  }
 
-  int tap = 0, cc = 0;
-  int tap2 = 2, cc2 = 0;                       // (tap, cc) of chunk q + 2
 #pragma unroll 1
-  for (int q = 0; q < NQ; ++q) {
-    // Everything up to the weights of chunk q has landed.  Issued behind them and possibly still in flight: the weights of chunk
-    // q + 1 and the pieces of the next patch issued in iterations q - 2 and q - 1 (one per iteration, taps 0 .. npw - 1).
-    const bool nextp = cc + 1 < NCC && !(LBM_ABL(a.dbg & 1));
-    int allow = (q + 1 < NQ && !(LBM_ABL(a.dbg & 2))) ? nbw : 0;
-    if (nextp) allow += (tap >= 1 && tap - 1 < npw ? 1 : 0) + (tap >= 2 && tap - 2 < npw ? 1 : 0);
-    cp_wait(allow);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (this wave's fragment reads of chunk q - 1 are done, wherever hipcc put its MFMAs)
-    __builtin_amdgcn_s_barrier();
-    // every wave is done with chunk q - 1: its weight stage and the other patch buffer are free
-    if (q + 2 < NQ && !(LBM_ABL(a.dbg & 2))) issue_w(q + 2, tap2 * a.Cin + cc2 * 32);
-    if (nextp && tap < npw) issue_patch_piece(cc + 1, tap);
+  for (;;) {
+    const int itn = it + G;                    // the next item of this workgroup
+    const bool has_next = itn < a.items;
 
-    const unsigned char* P = lds + (cc & 1) * PATCHB;
-    const unsigned char* Bs = lds + OFF_B + (q % NB) * BSTAGE;
-    const int ky = tap / 3, kx = tap - 3 * ky;
-    const int tshift = ky * PW + kx;
-    half8 fah[2][2], fal[2][2], fbh[2], fbl[2];
+    f32x16 acc[2], acx[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int p = p0[i] + tshift;
-      const int off = p * 64 + ((h ^ ((p >> 2) & 3)) << 4);
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        fah[s][i] = *reinterpret_cast<const half8*>(P + (off ^ (s << 5)));
-        fal[s][i] = *reinterpret_cast<const half8*>(P + PLANE_P + (off ^ (s << 5)));
+      for (int e = 0; e < 16; ++e) acc[i][e] = acx[i][e] = 0.f;
+
+    int tap = 0, cc = 0;
+    int tap2 = 2, cc2 = 0;                     // (tap, cc) of chunk q + 2
+#pragma unroll 1
+    for (int q = 0; q < NQ; ++q) {
+      // DMA waves: everything up to the weights of chunk q has landed.  Issued behind them and possibly still in flight: the weights
+      // of chunk q + 1 and the pieces of the next patch issued in iterations q - 2 and q - 1 (one per iteration, taps 0 .. npw - 1).
+      const bool nextp = (cc + 1 < NCC || has_next) && !(LBM_ABL(a.dbg & 1));
+      if (dma_wave) {
+        int allow = (q + 1 < NQ && !(LBM_ABL(a.dbg & 2))) ? nbw : 0;
+        if (nextp) allow += (tap >= 1 && tap - 1 < npw ? 1 : 0) + (tap >= 2 && tap - 2 < npw ? 1 : 0);
+        cp_wait(allow);
       }
-    }
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      fbh[s] = *reinterpret_cast<const half8*>(Bs + (offB ^ (s << 5)));
-      fbl[s] = *reinterpret_cast<const half8*>(Bs + 8192 + (offB ^ (s << 5)));
-    }
-    if (!(LBM_ABL(a.dbg & 4)))
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
+      sync_lds();
+      // every wave is done with chunk q - 1 since this chunk's barrier: its weight stage and the other patch buffer are free.  The DMA
+      // goes out FIRST: issued behind the MFMAs it lands too late (layer-2 shape 174 -> 188 us)
+      if (dma_wave) {
+        if (q + 2 < NQ && !(LBM_ABL(a.dbg & 2))) issue_w(n0, (q + 2) % NB, tap2 * a.Cin + cc2 * 32);
+        if (nextp && tap < npw) {
+          if (cc + 1 < NCC) issue_patch_piece(b, y0, cc + 1, tap);
+          else {                                // (NCC is even: chunk 0 of the next item goes to buffer 0, idle now)
+            int bn, y0n, n0n;
+            long long m0n;
+            item_of(itn, bn, y0n, n0n, m0n);       // (worked out where it is used: kept across the loop it costs scalar registers)
+            issue_patch_piece(bn, y0n, 0, tap);
+          }
+        }
+      }
+
+      const unsigned char* P = patch_buf(cc);
+      const unsigned char* Bs = stage_w(q % NB);
+      const int ky = tap / 3, kx = tap - 3 * ky;
+      const int tshift = ky * PW + kx;
+      // fragments in the order the MFMAs want them (the waits count in issue order): k-step 0 first, weights before pixels
+      half8 fah[2][2], fal[2][2], fbh[2], fbl[2];
+      int offA[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[s][i], fbh[s], acc[i], 0, 0, 0);
-        acx[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[s][i], fbl[s], acx[i], 0, 0, 0);
-        acx[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[s][i], fbh[s], acx[i], 0, 0, 0);
+        const int p = p0[i] + tshift;
+        offA[i] = p * 64 + ((h ^ ((p >> 2) & 3)) << 4);
       }
-    if (++tap == 9) { tap = 0; ++cc; }
-    if (++tap2 == 9) { tap2 = 0; ++cc2; }
-  }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        fbh[s] = *reinterpret_cast<const half8*>(Bs + (offB ^ (s << 5)));
+        fah[s][0] = *reinterpret_cast<const half8*>(P + (offA[0] ^ (s << 5)));
+        fbl[s] = *reinterpret_cast<const half8*>(Bs + 8192 + (offB ^ (s << 5)));
+        fal[s][0] = *reinterpret_cast<const half8*>(P + PLANE_P + (offA[0] ^ (s << 5)));
+        fah[s][1] = *reinterpret_cast<const half8*>(P + (offA[1] ^ (s << 5)));
+        fal[s][1] = *reinterpret_cast<const half8*>(P + PLANE_P + (offA[1] ^ (s << 5)));
+      }
+      if (!(LBM_ABL(a.dbg & 4)))
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[s][i], fbh[s], acc[i], 0, 0, 0);
+          acx[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[s][i], fbl[s], acx[i], 0, 0, 0);
+          acx[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[s][i], fbh[s], acx[i], 0, 0, 0);
+        }
+      if (++tap == 9) { tap = 0; ++cc; }
+      if (++tap2 == 9) { tap2 = 0; ++cc2; }
+    }
 
-  // ---- epilogue: act(acc + bias) staged through LDS (everything staged above is dead), whole rows out, 16 bytes per lane ----
-  if (LBM_ABL(a.dbg & 8) && acc[0][0] != 12345.678f) return;
-  float* T = reinterpret_cast<float*>(lds);
-  __syncthreads();
-  {
-    const int cl = wn * 32 + r;
-    const float bv = a.bias ? a.bias[n0 + cl] : 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int rl = wm * 64 + i * 32 + 4 * h;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) T[(rl + (e & 3) + 8 * (e >> 2)) * TP + cl] = (acc[i][e] + acx[i][e] * (1.0f / 2048.0f)) + bv;
+    // ---- epilogue: act(acc + bias) through LDS in slices of 64 rows (patch buffer 1: idle since the last chunk), whole rows out,
+    // 16 bytes per lane, by the storing waves; meanwhile the DMA waves have the next item's first weight chunks on their way ----
+    sync_lds();                                // every wave is done with the last chunk: patch 1 and all weight stages are free
+    if (dma_wave && has_next && !(LBM_ABL(a.dbg & 2))) {
+      const int n0n = (itn % ntn) * 128;
+      issue_w(n0n, 0, 0);
+      issue_w(n0n, 1, a.Cin);
     }
-  }
-  __syncthreads();
+    if (!(LBM_ABL(a.dbg & 8))) {
+      float* T = reinterpret_cast<float*>(lds + OFF_P1);
+      const float bv = a.bias ? a.bias[n0 + wn * 32 + r] : 0.f;
+#pragma unroll 1
+      for (int j = 0; j < NWM; ++j) {
+        if (j > 0) sync_lds();                 // the slice before has been read
+        if (wm == j) {
+          const int cl = wn * 32 + r;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int c = tid + k * (NW * 64);
-    const int rl = c >> 5, c4 = c & 31;
-    const long long o = (m0 + rl) * a.Cout + n0 + c4 * 4;
-    float4 v = *reinterpret_cast<const float4*>(T + rl * TP + c4 * 4);
-    if (a.res) {
-      const float4 p = ld4(a.res + o);
-      v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+          for (int i = 0; i < 2; ++i) {
+            const int rl = i * 32 + 4 * h;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) T[(rl + (e & 3) + 8 * (e >> 2)) * TP + cl] = (acc[i][e] + acx[i][e] * (1.0f / 2048.0f)) + bv;
+          }
+        }
+        sync_lds();
+        if (!dma_wave) {
+          for (int c = tid - ND * 64; c < 64 * 32; c += ND * 64) {
+            const int rl = c >> 5, c4 = c & 31;
+            const long long o = (m0 + j * 64 + rl) * a.Cout + n0 + c4 * 4;
+            float4 v = *reinterpret_cast<const float4*>(T + rl * TP + c4 * 4);
+            if (a.res) {
+              const float4 p = ld4(a.res + o);
+              v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+            }
+            if (a.relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+            if (a.Y) st4(a.Y + o, v);
+            if (a.Ys) st4_split(a.Ys, a.ys_plane, o, v);
+          }
+        }
+      }
     }
-    if (a.relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-    if (a.Y) st4(a.Y + o, v);
-    if (a.Ys) st4_split(a.Ys, a.ys_plane, o, v);
+    if (!has_next) break;
+    it = itn;
+    item_of(it, b, y0, n0, m0);
+    // (the next main loop starts with a barrier: the last slice has been read before chunk 0 lets patch 1 / weight stage 2 be refilled)
   }
 #endif
 }
@@ -269,7 +327,12 @@ int conv_patch(const ConvSSArgs& c, hipStream_t stream) {
   const int rows = conv_patch_rows(c, g_conv_patch_tile);
   LBM_REQUIRE(rows > 0, "conv_patch: %d image rows do not divide into tiles", c.H);
   const int BM = rows * c.Wd;
-  const dim3 grid(c.Cout / 128, (unsigned)(M / BM));
+  d.items = (int)(M / BM) * (c.Cout / 128);
+  // one workgroup per CU walks its items; the grid divides the items evenly where it can (768 items: 256 x 3, 512: 256 x 2)
+  int wgs = d.items < 256 ? d.items : 256;
+  const int per = (d.items + wgs - 1) / wgs;
+  wgs = (d.items + per - 1) / per;
+  const dim3 grid(wgs);
   const double mnk = (double)M * c.Cout * 9.0 * c.Cin;
   ProfScope prof("conv_patch", stream, 2.0 * mnk,
                  4.0 * ((double)M * c.Cin + (double)M * c.Cout * ((c.Y ? 1 : 0) + (c.Ys ? 1 : 0) + (c.res ? 1 : 0)) + 9.0 * c.Cin * c.Cout));

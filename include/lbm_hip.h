@@ -456,7 +456,7 @@ int lbm_hip_profile_end(lbm_hip_profile_entry* out, int32_t cap);
  *  25  gemm_rs LDS ring: 3 (default) or 4 stages (steps fetched two / three ahead); bit-identical, measured equal
  *  26  conv_patch (3 x 3 convolutions 128 -> 128 / 256 -> 256 of many frames; key 4: 21 = never, 22 = whenever the shape admits it):
  *      bits 8.. = pixels per tile (192 / 256, 0 = chosen by the launcher), bits 0-7 timing-only ablation (tuning build): 1 no patch DMA
- *      after the first, 2 no weight DMA after the prologue, 4 no MFMAs, 8 no epilogue                                                   */
+ *      after the first, 2 no weight DMA after the prologue, 4 no MFMAs, 8 no epilogue, 16 no barrier in the main loop, 32 no DMA waits                                                 */
 int lbm_hip_debug_set(int32_t key, int32_t value);
 /* The knobs that currently differ from their defaults (what a measurement must state beside its figure; bench.py prints them
  * in `config.knobs` and refuses a headline when any is set): writes up to `cap` (key, value) pairs, returns how many there are. */

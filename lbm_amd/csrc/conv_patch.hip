@@ -37,7 +37,7 @@ struct ConvPatchDev {
   const _Float16* zeros;
   int H, Cin, Cout, relu, cin_log2;
   int items;   // (tiles of pixels) x (blocks of 128 output channels), output-channel block fastest
-  int dbg;   // tuning (timing only, debug key 26): 1 no patch DMA after the first, 2 no weight DMA after the prologue, 4 no MFMAs, 8 no epilogue
+  int dbg;   // tuning (timing only, debug key 26): 1 no patch DMA after the first, 2 no weight DMA after the prologue, 4 no MFMAs, 8 no epilogue, 16 no barrier in the main loop, 32 no DMA waits
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_cp;
@@ -187,9 +187,9 @@ __global__ __launch_bounds__(TR * WO * 4) void conv_patch_kernel(ConvPatchDev a)
       if (dma_wave) {
         int allow = (q + 1 < NQ && !(LBM_ABL(a.dbg & 2))) ? nbw : 0;
         if (nextp) allow += (tap >= 1 && tap - 1 < npw ? 1 : 0) + (tap >= 2 && tap - 2 < npw ? 1 : 0);
-        cp_wait(allow);
+        if (!(LBM_ABL(a.dbg & 32))) cp_wait(allow);
       }
-      sync_lds();
+      if (!(LBM_ABL(a.dbg & 16))) sync_lds();
       // every wave is done with chunk q - 1 since this chunk's barrier: its weight stage and the other patch buffer are free.  The DMA
       // goes out FIRST: issued behind the MFMAs it lands too late (layer-2 shape 174 -> 188 us)
       if (dma_wave) {

@@ -35,10 +35,10 @@ for (B, H, W, Cin, Cout, k, st) in [(64, 48, 64, 128, 128, 3, 1), (64, 24, 32, 2
         t_tiled = timeit(lambda: hip.conv2d_nhwc_ss(x, w, b, k, st, k // 2, True))
         lib.lbm_hip_debug_set(4, 22)
         row = []
-        for dbg in (0, 1, 2, 3, 4, 8, 3 + 8, 4 + 8, 15):
+        for dbg in (0, 1, 2, 3, 4, 8, 3 + 8, 4 + 8, 15, 16, 32, 48, 3 + 8 + 16):
             assert lib.lbm_hip_debug_set(26, dbg) == 0
             row.append(timeit(lambda: hip.conv2d_nhwc_ss(x, w, b, k, st, k // 2, True)))
         lib.lbm_hip_debug_set(26, 0)
         lib.lbm_hip_debug_set(4, 0)
         print((B, H, W, Cin, Cout), "tiled %.1f | patch %.1f | no patch DMA %.1f | no weight DMA %.1f | no DMA %.1f | no MFMA %.1f | no epilogue %.1f | "
-              "no DMA, no epilogue %.1f | DMA only %.1f | skeleton %.1f us" % tuple([t_tiled] + row), flush=True)
+              "no DMA, no epilogue %.1f | DMA only %.1f | skeleton %.1f | no barrier %.1f | no DMA waits %.1f | neither %.1f | no DMA, epilogue, barrier %.1f us" % tuple([t_tiled] + row), flush=True)

@@ -9,6 +9,8 @@ SHAPES = [(1024, 1024, 256), (1024, 256, 1024), (1024, 432, 256), (1024, 256, 25
           (9216, 256, 1024), (16320, 1536, 256), (1024, 12288, 256), (12288, 256, 192), (16384, 1024, 256), (16384, 256, 1024)]
 
 
+if os.environ.get("SHAPES"):          # e.g. SHAPES=16384x256x1024,147456x256x1024
+    SHAPES = [tuple(int(v) for v in t.split("x")) for t in os.environ["SHAPES"].split(",")]
 TILES = [int(v) for v in os.environ.get("TILES", "1,2,3,4,5,6,7,8,9").split(",")]
 
 

@@ -499,6 +499,10 @@ def main():
                 return e2
             extra["c3_per_rank"] = per_rank_entry("c3", min(args.steps, 20))
         nprof = min(args.steps, 20)
+        if world > 1 and rank == 0 and not args.no_profile:
+            # the line's `roofline` at N > 1 as well: rank 0's per-kernel HIP-event pass over its own (identical) workload, after every
+            # collective of the run; the other ranks wait in the closing barrier meanwhile
+            prof = r.profile(nprof)
         if world == 1:
             # p50 per-frame latency: each (serial) frame synchronised on its own; and the same with the frame step replayed as a
             # HIP graph: what a latency-bound caller would run; reported beside the eager figure, never instead of it

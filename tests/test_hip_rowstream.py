@@ -89,6 +89,38 @@ def test_correlation_top_k_equals_dense_product_and_dense_top_k(hip, B, N, h, w,
     assert torch.equal(ref, dr.view_as(ref))
 
 
+@pytest.mark.parametrize("shape", ["ascending", "descending", "bump", "plateaus"])
+@pytest.mark.parametrize("k", [9, 4])
+def test_correlation_top_k_on_rows_that_keep_the_lists_busy(hip, shape, k):
+    """Score rows on which a lane's list changes at every cell (ascending), never after the first k (descending), in runs (a smooth
+    bump: what a real correlation row looks like) or among long runs of exactly equal scores: the per-lane lists of the fused kernel
+    must end up as the dense product + dense top-k, ties cut at the lowest cell."""
+    h, w, N = 96, 128, 520
+    P0 = h * w
+    g = torch.Generator().manual_seed(17)
+    d = torch.nn.functional.normalize(torch.randn(256, generator=g), dim=0)
+    qf = torch.nn.functional.normalize(d[None, None] + 0.2 * torch.randn(1, N, 256, generator=g), dim=-1)
+    c = torch.arange(P0, dtype=torch.float32)
+    if shape == "ascending":
+        amp = 0.2 + 0.8 * c / P0
+    elif shape == "descending":
+        amp = 1.0 - 0.8 * c / P0
+    elif shape == "bump":
+        yy, xx = c // w, c % w
+        amp = 0.2 + torch.exp(-((yy - 40.0) ** 2 + (xx - 77.0) ** 2) / 200.0)
+    else:
+        amp = 0.25 * (1 + (c // 37) % 4)                 # runs of 37 equal cells, four levels
+    Ff = amp[None, :, None] * d[None, None]              # every cell the same direction: scores follow amp exactly, ties included
+    if shape != "plateaus":
+        Ff = Ff + 0.002 * torch.randn(1, P0, 256, generator=g)
+    q, F = _split(hip, qf.cuda()), _split(hip, Ff.cuda())
+    idx, ref, val = hip.corr_topk(q, F, k, w)
+    di, dr, dv = _dense(hip, q, F, k, w)
+    assert torch.equal(idx, di.view_as(idx)), (shape, k)
+    assert torch.equal(val.view(torch.int32), dv.view_as(val).view(torch.int32)), (shape, k)
+    assert torch.equal(ref, dr.view_as(ref)), (shape, k)
+
+
 def test_correlation_top_k_breaks_exact_ties_to_the_lowest_cell(hip):
     """Identical map rows give exactly equal scores.  Copies are planted in the same half-wave, the other half-wave (rows 4 apart),
     another step (32 apart), another cell range, and as a run of 12 equal cells that must be cut at k."""
